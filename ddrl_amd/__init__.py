@@ -1,0 +1,8 @@
+"""ddrl_amd -- MI355X-native (gfx950) implementation of ddrl's learning hot path.
+
+The product is ddrl_amd/libddrl_pop.so (hand-written HIP kernels behind the C ABI declared in
+include/ddrl_pop.h).  This package is the thin Python mirror of that ABI used by tests and bench.py;
+it has no CPU path and raises if the library is missing.
+"""
+from .lib import load, LibraryMissing, DdrlError  # noqa: F401
+from .population import DdpgConfig, DdpgPopulation  # noqa: F401

@@ -1,0 +1,713 @@
+// pop.hip -- host side of libddrl_pop.so: handle, device memory, the C ABI of include/ddrl_pop.h.
+// All arithmetic of the hot path runs in the gfx950 kernels (kernels_*.hip); there is no CPU
+// fallback: without a HIP device every create call fails with DDRL_EHIP.
+#include "../../include/ddrl_pop.h"
+#include "pop_internal.h"
+#include "host_util.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <vector>
+
+extern "C" {
+hipError_t ddpg_update_launch(const DdpgParams *P, hipStream_t st);
+size_t ddpg_update_lds_bytes(const DdpgParams *P);
+hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B, const uint8_t *mask,
+                              int *idx_out, hipStream_t st);
+hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, hipStream_t st);
+hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap, int rowlen, int S, int A,
+                                const float *s, const float *a, const float *r, const float *s2,
+                                const uint8_t *goal, const uint8_t *mask, hipStream_t st);
+hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, float *actions,
+                        const float *in_gate, const float *out_gate, int G, hipStream_t st);
+hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st);
+hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat, float *nbr,
+                            int stride, const uint8_t *flag, int G, hipStream_t st);
+hipError_t ewc_cost_launch(const float *w, const float *wstar, const float *fhat, int stride, float *out, int G,
+                           hipStream_t st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-net host bookkeeping of the EWC life-cycle (DODevMLP.hpp:803-822)
+struct EwcHost {
+  bool enabled = false;
+  std::vector<double> best_score, decay_mult;
+  std::vector<int> last_update_best;
+  std::vector<uint8_t> best_valid, live;
+};
+
+struct TrainNet {
+  NetDesc nd;
+  NetState st;           // device pointers
+  EwcHost ewc;
+  float *d_lr = nullptr, *d_decay = nullptr;
+};
+
+struct ddrl_pop {
+  ddrl_ddpg_config cfg;
+  int G = 0, device = 0;
+  hipStream_t stream = nullptr;
+  TrainNet net[2];                 // 0 actor, 1 critic  (targets hang off st.wt)
+  // replay
+  int rowlen = 0;
+  float *d_rep = nullptr;
+  int *d_len = nullptr, *d_head = nullptr;
+  std::vector<int> h_len, h_head;
+  uint32_t *d_mt = nullptr;
+  int *d_mtpos = nullptr;
+  int *d_idx = nullptr;
+  // hyper
+  float *d_tau = nullptr, *d_omtau = nullptr, *d_gamma = nullptr;
+  // diagnostics
+  float *d_loss = nullptr, *d_qt = nullptr, *d_dact = nullptr;
+  // staging
+  float *d_s = nullptr, *d_a = nullptr, *d_r = nullptr, *d_s2 = nullptr, *d_act = nullptr, *d_cost = nullptr;
+  uint8_t *d_goal = nullptr, *d_mask = nullptr, *d_flag = nullptr;
+  std::vector<void *> allocs;
+  DdpgParams P;
+};
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return ddrl_fail(DDRL_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+static int dalloc(ddrl_pop *h, T **p, size_t n, bool zero = true) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) return ddrl_fail(DDRL_ENOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+  h->allocs.push_back(q);
+  if (zero) {
+    e = hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream);
+    if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "hipMemset: %s", hipGetErrorString(e));
+  }
+  *p = (T *)q;
+  return DDRL_OK;
+}
+
+static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout, int hidden_act, int out_act) {
+  memset(&nd, 0, sizeof(nd));
+  nd.L = nh + 1;
+  nd.d[0] = d0;
+  for (int i = 0; i < nh; ++i) nd.d[i + 1] = hidden[i];
+  nd.d[nh + 1] = dout;
+  int off = 0, np = 0;
+  for (int l = 0; l < nd.L; ++l) {
+    nd.kp[l] = ddrl_roundup(nd.d[l], 4);
+    nd.offw[l] = off; off += nd.d[l + 1] * nd.kp[l];
+    nd.offb[l] = off; off += ddrl_roundup(nd.d[l + 1], 4);
+    np += nd.d[l + 1] * nd.d[l] + nd.d[l + 1];
+  }
+  for (int i = 0; i <= nd.L; ++i) nd.ld[i] = ddrl_ldpad(nd.d[i]);
+  nd.stride = ddrl_roundup(off, 64);
+  nd.np = np;
+  nd.hidden_act = hidden_act;
+  nd.out_act = out_act;
+}
+
+// flat reference order <-> padded device image of ONE agent
+static void pack_flat(const NetDesc &nd, const double *flat, float *img) {
+  size_t k = 0;
+  for (int l = 0; l < nd.L; ++l) {
+    for (int n = 0; n < nd.d[l + 1]; ++n)
+      for (int c = 0; c < nd.d[l]; ++c) img[nd.offw[l] + n * nd.kp[l] + c] = (float)flat[k++];
+    for (int n = 0; n < nd.d[l + 1]; ++n) img[nd.offb[l] + n] = (float)flat[k++];
+  }
+}
+static void unpack_flat(const NetDesc &nd, const float *img, double *flat) {
+  size_t k = 0;
+  for (int l = 0; l < nd.L; ++l) {
+    for (int n = 0; n < nd.d[l + 1]; ++n)
+      for (int c = 0; c < nd.d[l]; ++c) flat[k++] = (double)img[nd.offw[l] + n * nd.kp[l] + c];
+    for (int n = 0; n < nd.d[l + 1]; ++n) flat[k++] = (double)img[nd.offb[l] + n];
+  }
+}
+
+static int upload_flat(ddrl_pop *h, const NetDesc &nd, float *dst, const double *flat) {
+  std::vector<float> img((size_t)h->G * nd.stride, 0.f);
+  for (int g = 0; g < h->G; ++g) pack_flat(nd, flat + (size_t)g * nd.np, img.data() + (size_t)g * nd.stride);
+  HIPCHK(hipMemcpyAsync(dst, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+static int download_flat(ddrl_pop *h, const NetDesc &nd, const float *src, double *flat) {
+  std::vector<float> img((size_t)h->G * nd.stride);
+  HIPCHK(hipMemcpyAsync(img.data(), src, img.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int g = 0; g < h->G; ++g) unpack_flat(nd, img.data() + (size_t)g * nd.stride, flat + (size_t)g * nd.np);
+  return DDRL_OK;
+}
+
+template <class T>
+static int upload_vec(ddrl_pop *h, T *dst, const std::vector<T> &v) {
+  HIPCHK(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+static int upload_mask(ddrl_pop *h, const uint8_t *mask, const uint8_t **dmask) {
+  *dmask = nullptr;
+  if (!mask) return DDRL_OK;
+  HIPCHK(hipMemcpyAsync(h->d_mask, mask, h->G, hipMemcpyHostToDevice, h->stream));
+  *dmask = h->d_mask;
+  return DDRL_OK;
+}
+
+static int set_device(ddrl_pop *h) {
+  HIPCHK(hipSetDevice(h->device));
+  return DDRL_OK;
+}
+
+static TrainNet *train_net(ddrl_pop *h, int net) { return (net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET) ? &h->net[0] : &h->net[1]; }
+static float *net_weights(ddrl_pop *h, int net) {
+  TrainNet *t = train_net(h, net);
+  return (net == DDRL_NET_ACTOR || net == DDRL_NET_CRITIC) ? t->st.w : t->st.wt;
+}
+
+static int refresh_ewc_coef(ddrl_pop *h, TrainNet &t) {
+  if (!t.ewc.enabled) return DDRL_OK;
+  std::vector<float> c(h->G);
+  for (int g = 0; g < h->G; ++g) {
+    double f = h->cfg.ewc_decay >= 0. ? t.ewc.decay_mult[g] : 1.;   // DODevMLP.hpp:691-693
+    c[g] = t.ewc.live[g] ? (float)(h->cfg.ewc * f) : 0.f;
+  }
+  return upload_vec(h, t.st.ewc_coef, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" const char *ddrl_version(void) { return "ddrl_amd 0.1 (gfx950)"; }
+
+extern "C" int ddrl_ddpg_config_default(ddrl_ddpg_config *c) {
+  if (!c) return ddrl_fail(DDRL_EINVAL, "cfg is NULL");
+  memset(c, 0, sizeof(*c));
+  c->n_agents = 1; c->nb_sensors = 18; c->nb_motors = 6;
+  c->n_hidden_a = 2; c->hidden_unit_a[0] = 100; c->hidden_unit_a[1] = 100;
+  c->n_hidden_q = 2; c->hidden_unit_q[0] = 100; c->hidden_unit_q[1] = 100;
+  c->mini_batch_size = 64; c->replay_memory = 10000; c->inverting_grad = 1; c->force_more_update = 0;
+  c->hidden_layer_type = 1; c->actor_output_layer_type = 2; c->momentum = 0; c->nstep_return = 0;
+  c->gamma = 0.99; c->tau_soft_update = 0.001; c->alpha_a = 1e-4; c->alpha_v = 1e-3; c->decay_v = -1.;
+  c->ewc = -1.; c->ewc_decay = -1.; c->ewc_fisher_beta = 0.999; c->ewc_best_param_method = 0; c->ewc_for_critic = 0;
+  c->device = -1;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *c) {
+  if (!path || !c) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  DdrlIni ini;
+  std::string err;
+  if (!ini.load(path, &err)) return ddrl_fail(DDRL_EIO, "%s", err.c_str());
+  const int G = c->n_agents, S = c->nb_sensors, A = c->nb_motors, dev = c->device;
+  ddrl_ddpg_config_default(c);
+  c->n_agents = G > 0 ? G : 1;
+  if (S > 0) c->nb_sensors = S;
+  if (A > 0) c->nb_motors = A;
+  c->device = dev;
+  try {
+    std::vector<long> hq = ini.get_list("agent.hidden_unit_q"), ha = ini.get_list("agent.hidden_unit_a");
+    if (hq.empty() || ha.empty() || hq.size() > DDRL_MAX_HIDDEN || ha.size() > DDRL_MAX_HIDDEN)
+      return ddrl_fail(DDRL_EINVAL, "hidden_unit_q/a: 1..%d layers supported", DDRL_MAX_HIDDEN);
+    c->n_hidden_q = (int)hq.size(); for (size_t i = 0; i < hq.size(); ++i) c->hidden_unit_q[i] = (int)hq[i];
+    c->n_hidden_a = (int)ha.size(); for (size_t i = 0; i < ha.size(); ++i) c->hidden_unit_a[i] = (int)ha[i];
+    c->gamma = ini.get_double("agent.gamma");
+    c->mini_batch_size = (int)ini.get_long("agent.mini_batch_size");
+    c->replay_memory = (int)ini.get_long("agent.replay_memory");
+    c->inverting_grad = ini.get_bool("agent.inverting_grad");
+    c->force_more_update = (int)ini.get_long("agent.force_more_update");
+    c->tau_soft_update = ini.get_double("agent.tau_soft_update");
+    c->alpha_a = ini.get_double("agent.alpha_a");
+    c->alpha_v = ini.get_double("agent.alpha_v");
+    c->decay_v = ini.get_double("agent.decay_v");
+    c->batch_norm_critic = (int)ini.get_long("agent.batch_norm_critic");
+    c->batch_norm_actor = (int)ini.get_long("agent.batch_norm_actor");
+    c->actor_output_layer_type = (int)ini.get_long("agent.actor_output_layer_type");
+    c->hidden_layer_type = (int)ini.get_long("agent.hidden_layer_type");
+    c->momentum = (int)ini.get_long("agent.momentum");
+    c->nstep_return = (int)ini.get_long("agent.nstep_return");
+    if (ini.has("devnn.ewc")) c->ewc = ini.get_double("devnn.ewc");
+    if (c->ewc >= 0.) {
+      if (ini.has("devnn.ewc_decay")) c->ewc_decay = ini.get_double("devnn.ewc_decay");
+      c->ewc_fisher_beta = ini.get_double("devnn.ewc_fisher_beta");
+      c->ewc_best_param_method = (int)ini.get_long("devnn.ewc_best_param_method");
+      c->ewc_for_critic = (int)ini.get_long("devnn.ewc_for_critic");
+    }
+  } catch (const std::exception &e) {
+    return ddrl_fail(DDRL_EIO, "%s: %s", path, e.what());
+  }
+  return DDRL_OK;
+}
+
+static int validate(const ddrl_ddpg_config *c) {
+  if (c->n_agents < 1) return ddrl_fail(DDRL_EINVAL, "n_agents < 1");
+  if (c->nb_sensors < 1 || c->nb_motors < 1) return ddrl_fail(DDRL_EINVAL, "nb_sensors/nb_motors < 1");
+  if (c->nb_sensors + c->nb_motors > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "nb_sensors + nb_motors > %d", DDRL_MAXW);
+  if (c->n_hidden_a < 1 || c->n_hidden_a > DDRL_MAX_HIDDEN || c->n_hidden_q < 1 || c->n_hidden_q > DDRL_MAX_HIDDEN)
+    return ddrl_fail(DDRL_EINVAL, "1..%d hidden layers supported", DDRL_MAX_HIDDEN);
+  for (int i = 0; i < c->n_hidden_a; ++i)
+    if (c->hidden_unit_a[i] < 1 || c->hidden_unit_a[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_a[%d]=%d outside 1..%d (fused kernel limit)", i, c->hidden_unit_a[i], DDRL_MAXW);
+  for (int i = 0; i < c->n_hidden_q; ++i)
+    if (c->hidden_unit_q[i] < 1 || c->hidden_unit_q[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_q[%d]=%d outside 1..%d (fused kernel limit)", i, c->hidden_unit_q[i], DDRL_MAXW);
+  if (c->mini_batch_size < 1 || c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "mini_batch_size outside 1..%d", DDRL_MB);
+  if (c->replay_memory < c->mini_batch_size) return ddrl_fail(DDRL_EINVAL, "replay_memory < mini_batch_size");
+  if (c->hidden_layer_type < 1 || c->hidden_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "hidden_layer_type not in (1,2,3)");
+  if (c->actor_output_layer_type < 0 || c->actor_output_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "actor_output_layer_type not in 0..3");
+  if (c->momentum < 0 || c->momentum > 3) return ddrl_fail(DDRL_EINVAL, "momentum not in 0..3");
+  if (c->nstep_return > 0) return ddrl_fail(DDRL_EINVAL, "nstep_return > 0 is not supported on the device path yet");
+  if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
+  if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
+  return DDRL_OK;
+}
+
+static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc) {
+  const size_t n = (size_t)h->G * t.nd.stride;
+  int rc;
+  if ((rc = dalloc(h, &t.st.w, n))) return rc;
+  if ((rc = dalloc(h, &t.st.m, n))) return rc;
+  if ((rc = dalloc(h, &t.st.v, n))) return rc;
+  if ((rc = dalloc(h, &t.st.wt, n))) return rc;
+  if ((rc = dalloc(h, &t.st.iter, h->G))) return rc;
+  if ((rc = dalloc(h, &t.d_lr, h->G))) return rc;
+  if ((rc = dalloc(h, &t.d_decay, h->G))) return rc;
+  t.st.lr = t.d_lr;
+  t.st.decay = t.d_decay;
+  t.ewc.enabled = ewc;
+  if (ewc) {
+    if ((rc = dalloc(h, &t.st.fisher, n))) return rc;
+    if ((rc = dalloc(h, &t.st.fhat, n))) return rc;
+    if ((rc = dalloc(h, &t.st.wstar, n))) return rc;
+    if ((rc = dalloc(h, &t.st.best, n))) return rc;
+    if ((rc = dalloc(h, &t.st.fisher_nbr, h->G))) return rc;
+    if ((rc = dalloc(h, &t.st.ewc_coef, h->G))) return rc;
+    t.ewc.best_score.assign(h->G, std::numeric_limits<double>::lowest());
+    t.ewc.decay_mult.assign(h->G, 1.0);
+    t.ewc.last_update_best.assign(h->G, 0);
+    t.ewc.best_valid.assign(h->G, 0);
+    t.ewc.live.assign(h->G, 0);
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed, ddrl_pop_t **out) {
+  if (!cfg || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  *out = nullptr;
+  int rc = validate(cfg);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return ddrl_fail(DDRL_EHIP, "no HIP device: libddrl_pop has no CPU path");
+  ddrl_pop *h = new ddrl_pop();
+  h->cfg = *cfg;
+  h->G = cfg->n_agents;
+  if (cfg->device >= 0) h->device = cfg->device;
+  else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+  auto bail = [&](int code) { ddrl_pop_destroy(h); return code; };
+  if ((rc = set_device(h))) return bail(rc);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "hipStreamCreate failed"));
+  const int G = h->G, S = cfg->nb_sensors, A = cfg->nb_motors, B = cfg->mini_batch_size;
+  // DeepQNAg.hpp:209-210 (actor) and :224-225 (critic: input = sensors + motors, 1 output, linear)
+  build_desc(h->net[0].nd, S, cfg->hidden_unit_a, cfg->n_hidden_a, A, cfg->hidden_layer_type, cfg->actor_output_layer_type);
+  build_desc(h->net[1].nd, S + A, cfg->hidden_unit_q, cfg->n_hidden_q, 1, cfg->hidden_layer_type, 0);
+  const bool ewc = cfg->ewc >= 0.;
+  if ((rc = alloc_net(h, h->net[0], ewc))) return bail(rc);
+  if ((rc = alloc_net(h, h->net[1], ewc && cfg->ewc_for_critic >= 1))) return bail(rc);   // DODevMLP.hpp:714-720
+  h->rowlen = ddrl_roundup(2 * S + A + 2, 4);
+  if ((rc = dalloc(h, &h->d_rep, (size_t)G * cfg->replay_memory * h->rowlen, false))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_len, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_head, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_mt, (size_t)G * 624))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_mtpos, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_idx, (size_t)G * B))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_tau, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_omtau, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_gamma, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_loss, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_qt, (size_t)G * B))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_dact, (size_t)G * B * A))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_s, (size_t)G * S))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_s2, (size_t)G * S))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_a, (size_t)G * A))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_act, (size_t)G * A))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_r, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_cost, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_goal, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_mask, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_flag, G))) return bail(rc);
+  h->h_len.assign(G, 0);
+  h->h_head.assign(G, 0);
+
+  // hyper-parameter defaults
+  std::vector<double> v(G);
+  std::fill(v.begin(), v.end(), cfg->alpha_a); if ((rc = ddrl_pop_set_hyper(h, "alpha_a", v.data()))) return bail(rc);
+  std::fill(v.begin(), v.end(), cfg->alpha_v); if ((rc = ddrl_pop_set_hyper(h, "alpha_v", v.data()))) return bail(rc);
+  std::fill(v.begin(), v.end(), cfg->tau_soft_update); if ((rc = ddrl_pop_set_hyper(h, "tau_soft_update", v.data()))) return bail(rc);
+  std::fill(v.begin(), v.end(), cfg->gamma); if ((rc = ddrl_pop_set_hyper(h, "gamma", v.data()))) return bail(rc);
+  std::fill(v.begin(), v.end(), cfg->decay_v); if ((rc = ddrl_pop_set_hyper(h, "decay_v", v.data()))) return bail(rc);
+  {
+    std::vector<float> nod(G, -1.f);   // the actor never has weight decay (MLP.hpp:252-270)
+    if ((rc = upload_vec(h, h->net[0].d_decay, nod))) return bail(rc);
+  }
+  // replay engines: default seeds 0..G-1 (bib::Seed seeds from clock+thread id, Seed.hpp:52-54)
+  {
+    std::vector<uint32_t> seeds(G);
+    for (int g = 0; g < G; ++g) seeds[g] = (uint32_t)g;
+    if ((rc = ddrl_pop_seed_replay(h, seeds.data()))) return bail(rc);
+  }
+  // gaussian(0, 0.01) fill of W and b (MLP.hpp:936-944); targets are clones (DeepQNAg.hpp:216-234)
+  {
+    std::mt19937_64 eng(init_seed);
+    std::normal_distribution<double> nd01(0.0, 0.01);
+    for (int k = 0; k < 2; ++k) {
+      std::vector<double> flat((size_t)G * h->net[k].nd.np);
+      for (auto &x : flat) x = nd01(eng);
+      if ((rc = upload_flat(h, h->net[k].nd, h->net[k].st.w, flat.data()))) return bail(rc);
+      if ((rc = upload_flat(h, h->net[k].nd, h->net[k].st.wt, flat.data()))) return bail(rc);
+    }
+  }
+
+  // kernel parameter block
+  DdpgParams &P = h->P;
+  memset(&P, 0, sizeof(P));
+  P.a = h->net[0].nd; P.q = h->net[1].nd;
+  P.sa = h->net[0].st; P.sq = h->net[1].st;
+  P.G = G; P.S = S; P.A = A; P.B = B; P.cap = cfg->replay_memory; P.rowlen = h->rowlen;
+  P.inverting = cfg->inverting_grad ? 1 : 0;
+  P.ldxc = ddrl_ldpad(S + A); P.ldxa = ddrl_ldpad(S);
+  double b1, b2;   // MLP.hpp:160-173
+  switch (cfg->momentum) { case 0: b1 = 0.; b2 = 0.999; break; case 1: b1 = 0.9; b2 = 0.999; break;
+                           case 2: b1 = 0.; b2 = 0.; break; default: b1 = 0.9; b2 = 0.; }
+  P.beta1 = (float)b1; P.beta2 = (float)b2; P.omb1 = (float)(1. - b1); P.omb2 = (float)(1. - b2);
+  P.eps = 1e-8f;   // caffe SolverParameter.delta default
+  P.fisher_beta = (float)cfg->ewc_fisher_beta;
+  P.rep = h->d_rep; P.rep_len = h->d_len; P.rep_head = h->d_head; P.idx = h->d_idx;
+  P.tau = h->d_tau; P.omtau = h->d_omtau; P.gamma = h->d_gamma;
+  P.loss_out = h->d_loss; P.qt_out = h->d_qt; P.dact_out = h->d_dact;
+  if (ddpg_update_lds_bytes(&P) > 160 * 1024) return bail(ddrl_fail(DDRL_EINVAL, "network too wide for the LDS-resident kernel (%zu bytes of LDS)", ddpg_update_lds_bytes(&P)));
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "sync failed"));
+  *out = h;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_destroy(ddrl_pop_t *h) {
+  if (!h) return DDRL_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_sync(ddrl_pop_t *h) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *v) {
+  if (!h || !key || !v) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int G = h->G;
+  std::vector<float> f(G);
+  std::string k(key);
+  if (k == "alpha_a" || k == "alpha_v") {
+    for (int g = 0; g < G; ++g) { if (!(v[g] > 0)) return ddrl_fail(DDRL_EINVAL, "%s[%d] <= 0", key, g); f[g] = (float)v[g]; }
+    return upload_vec(h, k == "alpha_a" ? h->net[0].d_lr : h->net[1].d_lr, f);
+  }
+  if (k == "tau_soft_update") {
+    std::vector<float> om(G);
+    // MLP.hpp:449-450: axpby(tau, from, (1.f - tau), to) -- (1.f - tau) evaluated in double
+    for (int g = 0; g < G; ++g) { f[g] = (float)v[g]; om[g] = (float)(1.f - v[g]); }
+    if ((rc = upload_vec(h, h->d_tau, f))) return rc;
+    return upload_vec(h, h->d_omtau, om);
+  }
+  if (k == "gamma") { for (int g = 0; g < G; ++g) f[g] = (float)v[g]; return upload_vec(h, h->d_gamma, f); }
+  if (k == "decay_v") { for (int g = 0; g < G; ++g) f[g] = (float)v[g]; return upload_vec(h, h->net[1].d_decay, f); }
+  return ddrl_fail(DDRL_EINVAL, "unknown hyper-parameter '%s'", key);
+}
+
+extern "C" int ddrl_pop_num_params(ddrl_pop_t *h, int net) {
+  if (!h || net < 0 || net > 3) return ddrl_fail(DDRL_EINVAL, "bad handle/net");
+  return train_net(h, net)->nd.np;
+}
+
+extern "C" int ddrl_pop_set_weights(ddrl_pop_t *h, int net, const double *flat) {
+  if (!h || !flat || net < 0 || net > 3) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  return upload_flat(h, train_net(h, net)->nd, net_weights(h, net), flat);
+}
+
+extern "C" int ddrl_pop_get_weights(ddrl_pop_t *h, int net, double *flat) {
+  if (!h || !flat || net < 0 || net > 3) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  return download_flat(h, train_net(h, net)->nd, net_weights(h, net), flat);
+}
+
+extern "C" int ddrl_pop_get_adam(ddrl_pop_t *h, int net, double *m, double *v, int32_t *iter) {
+  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic only");
+  int rc = set_device(h);
+  if (rc) return rc;
+  TrainNet *t = train_net(h, net);
+  if (m && (rc = download_flat(h, t->nd, t->st.m, m))) return rc;
+  if (v && (rc = download_flat(h, t->nd, t->st.v, v))) return rc;
+  if (iter) {
+    HIPCHK(hipMemcpyAsync(iter, t->st.iter, h->G * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_set_adam(ddrl_pop_t *h, int net, const double *m, const double *v, const int32_t *iter) {
+  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic only");
+  int rc = set_device(h);
+  if (rc) return rc;
+  TrainNet *t = train_net(h, net);
+  if (m && (rc = upload_flat(h, t->nd, t->st.m, m))) return rc;
+  if (v && (rc = upload_flat(h, t->nd, t->st.v, v))) return rc;
+  if (iter) {
+    HIPCHK(hipMemcpyAsync(t->st.iter, iter, h->G * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_seed_replay(ddrl_pop_t *h, const uint32_t *seeds) {
+  if (!h || !seeds) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  uint32_t *d_seeds = (uint32_t *)h->d_idx;   // G words of scratch (d_idx holds G*B >= G ints)
+  HIPCHK(hipMemcpyAsync(d_seeds, seeds, h->G * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(mt_seed_launch(h->d_mt, h->d_mtpos, d_seeds, h->G, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_replay_append(ddrl_pop_t *h, const float *s, const float *a, const float *r,
+                                      const float *s2, const uint8_t *goal, const uint8_t *mask) {
+  if (!h || !s || !a || !r || !s2 || !goal) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
+  const uint8_t *dmask;
+  if ((rc = upload_mask(h, mask, &dmask))) return rc;
+  HIPCHK(hipMemcpyAsync(h->d_s, s, (size_t)G * S * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_a, a, (size_t)G * A * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_r, r, (size_t)G * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_s2, s2, (size_t)G * S * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_goal, goal, (size_t)G, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(replay_append_launch(h->d_rep, h->d_len, h->d_head, G, h->cfg.replay_memory, h->rowlen, S, A,
+                              h->d_s, h->d_a, h->d_r, h->d_s2, h->d_goal, dmask, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
+  for (int g = 0; g < G; ++g) {
+    if (mask && !mask[g]) continue;
+    if (h->h_len[g] >= h->cfg.replay_memory) h->h_head[g] = (h->h_head[g] + 1) % h->cfg.replay_memory;
+    else h->h_len[g]++;
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_replay_load(ddrl_pop_t *h, int agent, int n, const float *rows) {
+  if (!h || !rows || agent < 0 || agent >= h->G || n < 0 || n > h->cfg.replay_memory)
+    return ddrl_fail(DDRL_EINVAL, "bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int S = h->cfg.nb_sensors, A = h->cfg.nb_motors, rl = 2 * S + A + 2;
+  std::vector<float> img((size_t)n * h->rowlen, 0.f);
+  for (int i = 0; i < n; ++i) memcpy(&img[(size_t)i * h->rowlen], rows + (size_t)i * rl, rl * sizeof(float));
+  HIPCHK(hipMemcpyAsync(h->d_rep + (size_t)agent * h->cfg.replay_memory * h->rowlen, img.data(),
+                        img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  h->h_len[agent] = n;
+  h->h_head[agent] = 0;
+  HIPCHK(hipMemcpyAsync(h->d_len + agent, &h->h_len[agent], sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_head + agent, &h->h_head[agent], sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_replay_len(ddrl_pop_t *h, int32_t *len) {
+  if (!h || !len) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(len, h->d_len, h->G * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_infer_dev(ddrl_pop_t *h, const float *d_states, float *d_actions) {
+  if (!h || !d_states || !d_actions) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIPCHK(infer_launch(&h->net[0].nd, h->net[0].st.w, d_states, d_actions, nullptr, nullptr, h->G, h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions) {
+  if (!h || !states || !actions) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
+  HIPCHK(hipMemcpyAsync(h->d_s, states, (size_t)G * S * 4, hipMemcpyHostToDevice, h->stream));
+  if ((rc = ddrl_pop_infer_dev(h, h->d_s, h->d_act))) return rc;
+  HIPCHK(hipMemcpyAsync(actions, h->d_act, (size_t)G * A * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int G = h->G, B = h->cfg.mini_batch_size;
+  const uint8_t *dmask;
+  if ((rc = upload_mask(h, mask, &dmask))) return rc;
+  if (idx) {
+    for (int g = 0; g < G; ++g) {
+      if (mask && !mask[g]) continue;
+      if (h->h_len[g] < 250 || h->h_len[g] < B) continue;
+      for (int i = 0; i < B; ++i)
+        if (idx[(size_t)g * B + i] < 0 || idx[(size_t)g * B + i] >= h->h_len[g])
+          return ddrl_fail(DDRL_EINVAL, "idx[%d][%d]=%d outside the replay of %d samples", g, i, idx[(size_t)g * B + i], h->h_len[g]);
+    }
+    HIPCHK(hipMemcpyAsync(h->d_idx, idx, (size_t)G * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIPCHK(replay_draw_launch(h->d_mt, h->d_mtpos, h->d_len, G, B, dmask, h->d_idx, h->stream));
+  }
+  h->P.mask = dmask;
+  h->P.sa = h->net[0].st;
+  h->P.sq = h->net[1].st;
+  HIPCHK(ddpg_update_launch(&h->P, h->stream));
+  if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *qt, float *dact) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const size_t G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;
+  if (idx) HIPCHK(hipMemcpyAsync(idx, h->d_idx, G * B * 4, hipMemcpyDeviceToHost, h->stream));
+  if (loss) HIPCHK(hipMemcpyAsync(loss, h->d_loss, G * 4, hipMemcpyDeviceToHost, h->stream));
+  if (qt) HIPCHK(hipMemcpyAsync(qt, h->d_qt, G * B * 4, hipMemcpyDeviceToHost, h->stream));
+  if (dact) HIPCHK(hipMemcpyAsync(dact, h->d_dact, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+// ---- EWC life-cycle ----
+extern "C" int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score, const uint8_t *mask) {
+  if (!h || !score) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  for (int k = 0; k < 2; ++k) {
+    TrainNet &t = h->net[k];
+    if (!t.ewc.enabled) continue;
+    std::vector<uint8_t> flag(h->G, 0);
+    bool any = false;
+    for (int g = 0; g < h->G; ++g) {
+      if (mask && !mask[g]) continue;
+      bool go = false, too_old;
+      EwcHost &e = t.ewc;
+      switch (h->cfg.ewc_best_param_method) {   // DODevMLP.hpp:726-747
+        case 3: e.last_update_best[g]++; go = e.last_update_best[g] == 1; break;
+        case 2: too_old = e.last_update_best[g] > 50; e.last_update_best[g]++;
+                go = (score[g] > e.best_score[g]) || too_old; if (go) e.last_update_best[g] = 0; break;
+        case 4: case 0: go = score[g] > e.best_score[g]; break;
+        case 1: go = true; break;
+      }
+      if (go) { e.best_score[g] = score[g]; e.best_valid[g] = 1; flag[g] = 1; any = true; }
+    }
+    if (!any) continue;
+    if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
+    HIPCHK(snapshot_launch(t.st.best, t.st.w, t.nd.stride, h->d_flag, h->G, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_ewc_setup(ddrl_pop_t *h, const uint8_t *mask) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  for (int k = 0; k < 2; ++k) {
+    TrainNet &t = h->net[k];
+    if (!t.ewc.enabled) continue;
+    std::vector<uint8_t> flag(h->G, 0);
+    bool any = false;
+    for (int g = 0; g < h->G; ++g) {
+      if (mask && !mask[g]) continue;
+      if (!t.ewc.best_valid[g]) continue;             // DODevMLP.hpp:605: best_param == nullptr
+      flag[g] = 1; any = true;
+      t.ewc.decay_mult[g] = 1.0;
+      t.ewc.best_score[g] = std::numeric_limits<double>::lowest();
+      t.ewc.live[g] = 1;
+    }
+    if (!any) continue;
+    if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
+    HIPCHK(ewc_setup_launch(t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride,
+                            h->d_flag, h->G, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = refresh_ewc_coef(h, t))) return rc;
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_ewc_decay_update(ddrl_pop_t *h, const uint8_t *mask) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  for (int k = 0; k < 2; ++k) {
+    TrainNet &t = h->net[k];
+    if (!t.ewc.enabled || !(h->cfg.ewc_decay >= 0.)) continue;   // DODevMLP.hpp:709-712
+    for (int g = 0; g < h->G; ++g)
+      if (!mask || mask[g]) t.ewc.decay_mult[g] *= h->cfg.ewc_decay;
+    if ((rc = refresh_ewc_coef(h, t))) return rc;
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost) {
+  if (!h || !cost || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  TrainNet &t = *train_net(h, net);
+  std::fill(cost, cost + h->G, 0.0);
+  if (!t.ewc.enabled) return DDRL_OK;
+  HIPCHK(ewc_cost_launch(t.st.w, t.st.wstar, t.st.fhat, t.nd.stride, h->d_cost, h->G, h->stream));
+  std::vector<float> c(h->G);
+  HIPCHK(hipMemcpyAsync(c.data(), h->d_cost, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int g = 0; g < h->G; ++g) {
+    if (!t.ewc.live[g]) continue;
+    double r = (double)c[g] * h->cfg.ewc / (double)t.nd.np;                // DODevMLP.hpp:679-683
+    cost[g] = h->cfg.ewc_decay < 0. ? r : r * t.ewc.decay_mult[g];
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat, double *wstar,
+                                double *fisher_nbr, double *decay_mult) {
+  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  TrainNet &t = *train_net(h, net);
+  if (!t.ewc.enabled) return ddrl_fail(DDRL_ESTATE, "EWC is not enabled for this net");
+  if (fisher && (rc = download_flat(h, t.nd, t.st.fisher, fisher))) return rc;
+  if (fisher_hat && (rc = download_flat(h, t.nd, t.st.fhat, fisher_hat))) return rc;
+  if (wstar && (rc = download_flat(h, t.nd, t.st.wstar, wstar))) return rc;
+  if (fisher_nbr) {
+    std::vector<float> f(h->G);
+    HIPCHK(hipMemcpyAsync(f.data(), t.st.fisher_nbr, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int g = 0; g < h->G; ++g) fisher_nbr[g] = f[g];
+  }
+  if (decay_mult) for (int g = 0; g < h->G; ++g) decay_mult[g] = t.ewc.decay_mult[g];
+  return DDRL_OK;
+}

@@ -1,0 +1,96 @@
+"""ctypes loader of libddrl_pop.so.  Fails loudly: there is no fallback."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libddrl_pop.so")
+DDRL_MAX_HIDDEN = 3
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class DdrlError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ddrl_pop error %d: %s" % (code, msg))
+        self.code = code
+
+
+class DdpgConfigC(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int), ("nb_sensors", C.c_int), ("nb_motors", C.c_int),
+        ("n_hidden_a", C.c_int), ("hidden_unit_a", C.c_int * DDRL_MAX_HIDDEN),
+        ("n_hidden_q", C.c_int), ("hidden_unit_q", C.c_int * DDRL_MAX_HIDDEN),
+        ("mini_batch_size", C.c_int), ("replay_memory", C.c_int), ("inverting_grad", C.c_int),
+        ("force_more_update", C.c_int), ("hidden_layer_type", C.c_int),
+        ("actor_output_layer_type", C.c_int), ("momentum", C.c_int), ("nstep_return", C.c_int),
+        ("batch_norm_actor", C.c_int), ("batch_norm_critic", C.c_int),
+        ("gamma", C.c_double), ("tau_soft_update", C.c_double), ("alpha_a", C.c_double),
+        ("alpha_v", C.c_double), ("decay_v", C.c_double),
+        ("ewc", C.c_double), ("ewc_decay", C.c_double), ("ewc_fisher_beta", C.c_double),
+        ("ewc_best_param_method", C.c_int), ("ewc_for_critic", C.c_int),
+        ("device", C.c_int),
+    ]
+
+
+# every symbol include/ddrl_pop.h declares: (name, restype, argtypes)
+_vp, _i, _cp = C.c_void_p, C.c_int, C.c_char_p
+SYMBOLS = [
+    ("ddrl_last_error", _cp, []),
+    ("ddrl_version", _cp, []),
+    ("ddrl_ddpg_config_default", _i, [C.POINTER(DdpgConfigC)]),
+    ("ddrl_ddpg_config_from_ini", _i, [_cp, C.POINTER(DdpgConfigC)]),
+    ("ddrl_ddpg_create", _i, [C.POINTER(DdpgConfigC), C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_pop_destroy", _i, [_vp]),
+    ("ddrl_pop_sync", _i, [_vp]),
+    ("ddrl_pop_set_hyper", _i, [_vp, _cp, _vp]),
+    ("ddrl_pop_num_params", _i, [_vp, _i]),
+    ("ddrl_pop_set_weights", _i, [_vp, _i, _vp]),
+    ("ddrl_pop_get_weights", _i, [_vp, _i, _vp]),
+    ("ddrl_pop_get_adam", _i, [_vp, _i, _vp, _vp, _vp]),
+    ("ddrl_pop_set_adam", _i, [_vp, _i, _vp, _vp, _vp]),
+    ("ddrl_pop_seed_replay", _i, [_vp, _vp]),
+    ("ddrl_pop_replay_append", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_pop_replay_load", _i, [_vp, _i, _i, _vp]),
+    ("ddrl_pop_replay_len", _i, [_vp, _vp]),
+    ("ddrl_pop_infer", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_infer_dev", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_ddpg_update", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_ddpg_last", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_pop_update_best_param", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_ewc_setup", _i, [_vp, _vp]),
+    ("ddrl_pop_ewc_decay_update", _i, [_vp, _vp]),
+    ("ddrl_pop_ewc_cost", _i, [_vp, _i, _vp]),
+    ("ddrl_pop_get_ewc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+]
+
+_lib = None
+
+
+def build():
+    """Compile libddrl_pop.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(HERE, "csrc")])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise LibraryMissing(
+            "%s not found: build it with `make -C ddrl_amd/csrc` (or __graft_entry__.build()). "
+            "ddrl_amd has no CPU path." % SO)
+    L = C.CDLL(SO)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)     # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise DdrlError(rc, load().ddrl_last_error().decode(errors="replace"))

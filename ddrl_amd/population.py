@@ -1,0 +1,173 @@
+"""Python mirror of the population C ABI (include/ddrl_pop.h) -- plumbing only.
+
+Names follow the reference's agent/MLP interface (DeepQNAg.hpp, MLP.hpp): nets ann / qnn /
+ann_target / qnn_target, copyWeightsTo/From, end_episode's update.  Arrays are numpy; the first
+axis is always the agent.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+
+NET_ACTOR, NET_CRITIC, NET_ACTOR_TARGET, NET_CRITIC_TARGET = 0, 1, 2, 3
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DdpgConfig:
+    """The [agent]/[devnn] keys of DeepQNAg::_unique_invoke (DeepQNAg.hpp:167-187)."""
+
+    def __init__(self, **kw):
+        self.c = _l.DdpgConfigC()
+        _l.check(_l.load().ddrl_ddpg_config_default(C.byref(self.c)))
+        for k, v in kw.items():
+            self.set(k, v)
+
+    @classmethod
+    def from_ini(cls, path, n_agents=1, nb_sensors=0, nb_motors=0):
+        o = cls()
+        o.c.n_agents, o.c.nb_sensors, o.c.nb_motors = n_agents, nb_sensors, nb_motors
+        _l.check(_l.load().ddrl_ddpg_config_from_ini(path.encode(), C.byref(o.c)))
+        return o
+
+    def set(self, k, v):
+        if k in ("hidden_unit_a", "hidden_unit_q"):
+            v = list(v)
+            if len(v) > _l.DDRL_MAX_HIDDEN:
+                raise ValueError("at most %d hidden layers" % _l.DDRL_MAX_HIDDEN)
+            arr = getattr(self.c, k)
+            for i, x in enumerate(v):
+                arr[i] = int(x)
+            setattr(self.c, "n_hidden_" + k[-1], len(v))
+        elif hasattr(self.c, k):
+            setattr(self.c, k, v)
+        else:
+            raise KeyError(k)
+
+    def get(self, k):
+        if k in ("hidden_unit_a", "hidden_unit_q"):
+            return list(getattr(self.c, k))[: getattr(self.c, "n_hidden_" + k[-1])]
+        return getattr(self.c, k)
+
+
+class DdpgPopulation:
+    """G independent DDPG agents on one GPU (DeepQNAg<MLP> x G)."""
+
+    def __init__(self, cfg, init_seed=0):
+        self.L = _l.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_ddpg_create(C.byref(cfg.c), init_seed, C.byref(h)))
+        self.h = h
+        self.G, self.S, self.A, self.B = cfg.c.n_agents, cfg.c.nb_sensors, cfg.c.nb_motors, cfg.c.mini_batch_size
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ddrl_pop_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sync(self):
+        _l.check(self.L.ddrl_pop_sync(self.h))
+
+    def set_hyper(self, key, values):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values, np.float64), (self.G,)))
+        _l.check(self.L.ddrl_pop_set_hyper(self.h, key.encode(), _p(v)))
+
+    def num_params(self, net):
+        n = self.L.ddrl_pop_num_params(self.h, net)
+        if n < 0:
+            _l.check(n)
+        return n
+
+    # MLP::copyWeightsFrom / copyWeightsTo
+    def set_weights(self, net, flat):
+        flat = np.ascontiguousarray(flat, np.float64).reshape(self.G, self.num_params(net))
+        _l.check(self.L.ddrl_pop_set_weights(self.h, net, _p(flat)))
+
+    def weights(self, net):
+        out = np.empty((self.G, self.num_params(net)))
+        _l.check(self.L.ddrl_pop_get_weights(self.h, net, _p(out)))
+        return out
+
+    def adam(self, net):
+        n = self.num_params(net)
+        m, v, it = np.empty((self.G, n)), np.empty((self.G, n)), np.empty(self.G, np.int32)
+        _l.check(self.L.ddrl_pop_get_adam(self.h, net, _p(m), _p(v), _p(it)))
+        return m, v, it
+
+    def set_adam(self, net, m, v, it):
+        m = np.ascontiguousarray(m, np.float64); v = np.ascontiguousarray(v, np.float64)
+        it = np.ascontiguousarray(it, np.int32)
+        _l.check(self.L.ddrl_pop_set_adam(self.h, net, _p(m), _p(v), _p(it)))
+
+    def seed_replay(self, seeds):
+        s = np.ascontiguousarray(seeds, np.uint32).reshape(self.G)
+        _l.check(self.L.ddrl_pop_seed_replay(self.h, _p(s)))
+
+    def replay_append(self, s, a, r, s2, goal, mask=None):
+        f = lambda x, n: np.ascontiguousarray(x, np.float32).reshape(self.G, n)
+        s, a, s2 = f(s, self.S), f(a, self.A), f(s2, self.S)
+        r = np.ascontiguousarray(r, np.float32).reshape(self.G)
+        goal = np.ascontiguousarray(goal, np.uint8).reshape(self.G)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_replay_append(self.h, _p(s), _p(a), _p(r), _p(s2), _p(goal), _p(m)))
+
+    def replay_load(self, agent, rows):
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 2 * self.S + self.A + 2)
+        _l.check(self.L.ddrl_pop_replay_load(self.h, agent, rows.shape[0], _p(rows)))
+
+    def replay_len(self):
+        out = np.empty(self.G, np.int32)
+        _l.check(self.L.ddrl_pop_replay_len(self.h, _p(out)))
+        return out
+
+    # ann_testing->computeOut(sensors) for every agent
+    def infer(self, states):
+        s = np.ascontiguousarray(states, np.float32).reshape(self.G, self.S)
+        out = np.empty((self.G, self.A), np.float32)
+        _l.check(self.L.ddrl_pop_infer(self.h, _p(s), _p(out)))
+        return out
+
+    # one pass of end_episode's fupd loop body for every (masked) agent
+    def update(self, idx=None, mask=None):
+        i = None if idx is None else np.ascontiguousarray(idx, np.int32).reshape(self.G, self.B)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_ddpg_update(self.h, _p(i), _p(m)))
+
+    def last(self):
+        idx = np.empty((self.G, self.B), np.int32)
+        loss = np.empty(self.G, np.float32)
+        qt = np.empty((self.G, self.B), np.float32)
+        da = np.empty((self.G, self.B, self.A), np.float32)
+        _l.check(self.L.ddrl_pop_ddpg_last(self.h, _p(idx), _p(loss), _p(qt), _p(da)))
+        return dict(idx=idx, loss=loss, q_targets=qt, dact=da)
+
+    def update_best_param(self, score, mask=None):
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(score, np.float64), (self.G,)))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        _l.check(self.L.ddrl_pop_update_best_param(self.h, _p(s), _p(m)))
+
+    def ewc_setup(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        _l.check(self.L.ddrl_pop_ewc_setup(self.h, _p(m)))
+
+    def ewc_decay_update(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        _l.check(self.L.ddrl_pop_ewc_decay_update(self.h, _p(m)))
+
+    def ewc_cost(self, net):
+        out = np.empty(self.G)
+        _l.check(self.L.ddrl_pop_ewc_cost(self.h, net, _p(out)))
+        return out
+
+    def ewc_state(self, net):
+        n = self.num_params(net)
+        f, fh, ws = np.empty((self.G, n)), np.empty((self.G, n)), np.empty((self.G, n))
+        nbr, dm = np.empty(self.G), np.empty(self.G)
+        _l.check(self.L.ddrl_pop_get_ewc(self.h, net, _p(f), _p(fh), _p(ws), _p(nbr), _p(dm)))
+        return dict(fisher=f, fisher_hat=fh, wstar=ws, fisher_nbr=nbr, decay_mult=dm)

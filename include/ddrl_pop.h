@@ -1,0 +1,143 @@
+/*
+ * ddrl_pop.h -- C ABI of libddrl_pop.so: the MI355X-native replacement of ddrl's learning hot path
+ * (the Caffe-backed MLP wrapper + the DDPG / NFAC(lambda)-V / CMA-ES update arithmetic above it),
+ * batched over a POPULATION of G independent agents.
+ *
+ * Plain C: opaque handles, pointers and sizes only.  Every function returns 0 on success and a
+ * negative DDRL_E* code on failure; ddrl_last_error() returns the message of the calling thread's
+ * last failure.  The library never calls exit() (the reference does: MLP.hpp:99-100, 352-355).
+ * One handle = one GPU = one HIP stream; calls on a handle are asynchronous on that stream and
+ * ordered; ddrl_pop_sync() waits.  A handle is thread-compatible, not thread-safe.
+ *
+ * Reference interface each entry point replaces is cited as path:line under /root/reference.
+ *
+ * Flat parameter order everywhere = the reference's learnable_params() order
+ * [W1 (out x in, row-major), b1, W2, b2, ...] (common/include/nn/MLP.hpp:623-676, pinned by
+ * common/src/test/CaffeUtest.cpp:24-55), ignore_null_lr=true view (gate weights excluded).
+ * Host-side arrays are double (the reference's type, MLP.hpp:623,651); device state is fp32.
+ */
+#ifndef DDRL_POP_H
+#define DDRL_POP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDRL_MAX_HIDDEN 3
+
+#define DDRL_OK            0
+#define DDRL_EINVAL       -1   /* bad argument / unsupported configuration */
+#define DDRL_EHIP         -2   /* HIP runtime error */
+#define DDRL_ENOMEM       -3
+#define DDRL_ESTATE       -4   /* call sequence error (e.g. update before enough samples) */
+#define DDRL_EIO          -5   /* ini file problems */
+
+/* nets of a DDPG population (DeepQNAg.hpp:209-234): ann, qnn, ann_target, qnn_target.
+ * ann_testing (DeepQNAg.hpp:221,469-472) is a full copy of ann after every update: aliased. */
+#define DDRL_NET_ACTOR          0
+#define DDRL_NET_CRITIC         1
+#define DDRL_NET_ACTOR_TARGET   2
+#define DDRL_NET_CRITIC_TARGET  3
+
+typedef struct ddrl_pop ddrl_pop_t;
+
+/* The [agent] ini keys DeepQNAg::_unique_invoke reads (DeepQNAg.hpp:167-187) + ARLAgent's
+ * (common/include/arch/ARLAgent.hpp:139-179), plus population-level fields.  Scalars here are the
+ * population defaults; per-agent values (a sweep) are set with ddrl_pop_set_hyper(). */
+typedef struct {
+  int    n_agents;                 /* G: population size on this GPU */
+  int    nb_sensors, nb_motors;    /* DeepQNAg ctor (DeepQNAg.hpp:95-98) */
+  int    n_hidden_a; int hidden_unit_a[DDRL_MAX_HIDDEN];   /* agent.hidden_unit_a */
+  int    n_hidden_q; int hidden_unit_q[DDRL_MAX_HIDDEN];   /* agent.hidden_unit_q */
+  int    mini_batch_size;          /* agent.mini_batch_size (<= 64, multiple of 16 in this round) */
+  int    replay_memory;            /* agent.replay_memory */
+  int    inverting_grad;           /* agent.inverting_grad */
+  int    force_more_update;        /* agent.force_more_update */
+  int    hidden_layer_type;        /* 1 leaky-ReLU(0.01), 2 tanh, 3 ReLU (MLP.hpp:798-803) */
+  int    actor_output_layer_type;  /* 0 linear, 1 leaky, 2 tanh, 3 ReLU (MLP.hpp:223-237) */
+  int    momentum;                 /* 0..3 -> Adam betas (MLP.hpp:160-173) */
+  int    nstep_return;             /* agent.nstep_return; only 0 supported on device this round */
+  int    batch_norm_actor, batch_norm_critic;  /* must be 0 this round (BatchNorm out of scope) */
+  double gamma;                    /* agent.gamma */
+  double tau_soft_update, alpha_a, alpha_v, decay_v;
+  /* [devnn] EWC keys (common/include/nn/DODevMLP.hpp:172-190); ewc < 0 disables */
+  double ewc, ewc_decay, ewc_fisher_beta;
+  int    ewc_best_param_method, ewc_for_critic;
+  int    device;                   /* HIP device ordinal; -1 = current */
+} ddrl_ddpg_config;
+
+const char *ddrl_last_error(void);
+const char *ddrl_version(void);
+
+/* fills *cfg with the defaults of BASELINE.md section 3 */
+int ddrl_ddpg_config_default(ddrl_ddpg_config *cfg);
+/* reads [agent] / [devnn] of a reference-format .ini (boost ini_parser syntax, list values a:b:c or
+ * a,b,c as bib::to_array, common/include/bib/IniParser.hpp:11-24) into *cfg.  Replaces
+ * DDPGAg_unique_invoke's config handling (agent/deepqn/src/pybinding/ddpg.cpp:17-45). Missing
+ * mandatory keys are an error (the reference throws from ptree::get). */
+int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *cfg);
+
+/* Replaces DDPGAg_new + _unique_invoke (ddpg.cpp:10-45; DeepQNAg.hpp:167-235): allocates the four
+ * nets of all G agents, Adam state, replay rings.  Weights are initialised ~N(0, 0.01^2) for W and
+ * b (MLP.hpp:936-944) from init_seed (not bit-matched to Caffe's RNG: parity runs inject weights). */
+int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed, ddrl_pop_t **out);
+int ddrl_pop_destroy(ddrl_pop_t *h);
+int ddrl_pop_sync(ddrl_pop_t *h);
+
+/* per-agent hyper-parameters: key in {"alpha_a","alpha_v","tau_soft_update","gamma","decay_v"} */
+int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *per_agent /* [G] */);
+
+/* MLP::number_of_parameters / copyWeightsFrom / copyWeightsTo (MLP.hpp:610-676), all agents:
+ * flat [G x n_params] doubles. */
+int ddrl_pop_num_params(ddrl_pop_t *h, int net);
+int ddrl_pop_set_weights(ddrl_pop_t *h, int net, const double *flat);
+int ddrl_pop_get_weights(ddrl_pop_t *h, int net, double *flat);
+/* Adam state of a trainable net (caffe SGDSolver history + Solver::iter, MLP.hpp:481-482,1127-1141) */
+int ddrl_pop_get_adam(ddrl_pop_t *h, int net, double *m, double *v, int32_t *iter /* [G] */);
+int ddrl_pop_set_adam(ddrl_pop_t *h, int net, const double *m, const double *v, const int32_t *iter);
+
+/* replay sampling engine: one std::mt19937 per agent (bib/Seed.hpp:47-57), seeded explicitly */
+int ddrl_pop_seed_replay(ddrl_pop_t *h, const uint32_t *seeds /* [G] */);
+
+/* DeepQNAg::insertSample's deque push (DeepQNAg.hpp:159-163): one transition per agent with
+ * mask[g] != 0 (mask NULL = all).  s,s2 [G x S], a [G x A], r [G], goal [G]. */
+int ddrl_pop_replay_append(ddrl_pop_t *h, const float *s, const float *a, const float *r,
+                           const float *s2, const uint8_t *goal, const uint8_t *mask);
+/* bulk load of n transitions into agent g's ring (benchmarks, resume): rows [n x (2S+A+2)] =
+ * s, a, s2, r, goal */
+int ddrl_pop_replay_load(ddrl_pop_t *h, int agent, int n, const float *rows);
+int ddrl_pop_replay_len(ddrl_pop_t *h, int32_t *len /* [G] */);
+
+/* MLP::computeOut on ann_testing (DeepQNAg.hpp:126; MLP.hpp:551-565) for all agents:
+ * states [G x S] -> actions [G x A].  Host buffers. */
+int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions);
+/* same with device-resident buffers (no PCIe in the loop) */
+int ddrl_pop_infer_dev(ddrl_pop_t *h, const float *d_states, float *d_actions);
+
+/* One pass of the `fupd` loop body of DeepQNAg::end_episode (DeepQNAg.hpp:343-466) for every agent
+ * with mask[g] != 0: sample B indices, gather, target forward passes, TD targets, critic Adam step,
+ * deterministic policy gradient through the critic, inverting gradients, EWC terms, actor Adam
+ * step, both soft target updates.  idx == NULL: indices are drawn on the device from each agent's
+ * mt19937 with the libstdc++-11 uniform_int_distribution algorithm (bit-exact with
+ * DeepQNAg.hpp:277).  idx != NULL: host array [G x B] of logical replay indices (0 = oldest).
+ * The guard of DeepQNAg.hpp:338 (len >= 250 && len >= B) is applied per agent on the device. */
+int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask);
+/* diagnostics of the last update: indices used [G x B], critic loss [G], TD targets [G x B],
+ * action gradients fed to the actor [G x B x A].  Any pointer may be NULL. */
+int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *q_targets, float *dact);
+
+/* EWC life-cycle (DODevMLP.hpp:604-758), per agent with mask[g] != 0 */
+int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score /* [G] */, const uint8_t *mask);
+int ddrl_pop_ewc_setup(ddrl_pop_t *h, const uint8_t *mask);
+int ddrl_pop_ewc_decay_update(ddrl_pop_t *h, const uint8_t *mask);
+int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost /* [G] */);
+/* fisher, fisher_hat (previous_fisher), wstar (best_param_previous_task): [G x n_params] */
+int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat, double *wstar,
+                     double *fisher_nbr /* [G] */, double *decay_mult /* [G] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+"""Builds a GPU population and G matching CPU-oracle agents on identical seeded inputs."""
+import numpy as np
+
+NETS = ("ann", "qnn", "ann_target", "qnn_target")
+
+
+def synth_transitions(rng, n, S, A):
+    """s,s' ~ U(-1,1)^S, a ~ U(-1,1)^A, r ~ N(0,1), goal ~ Bernoulli(0.01)."""
+    s = rng.uniform(-1, 1, (n, S)).astype(np.float32)
+    a = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+    s2 = rng.uniform(-1, 1, (n, S)).astype(np.float32)
+    r = rng.normal(0, 1, n).astype(np.float32)
+    goal = (rng.uniform(0, 1, n) < 0.01).astype(np.float32)
+    return np.concatenate([s, a, s2, r[:, None], goal[:, None]], axis=1)
+
+
+def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100), n_replay=1000,
+              replay_cap=2000, wscale=0.01, seed=0, hidden_act=1, actor_out_act=2, momentum=0,
+              inverting_grad=True, decay_v=-1.0, sweep=True, ewc=-1.0, ewc_decay=-1.0,
+              ewc_fisher_beta=0.999, ewc_for_critic=0, ewc_best_method=0):
+    import ddrl_amd
+    rng = np.random.RandomState(seed)
+    cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=B,
+                              replay_memory=replay_cap, hidden_unit_a=hidden_a, hidden_unit_q=hidden_q,
+                              hidden_layer_type=hidden_act, actor_output_layer_type=actor_out_act,
+                              momentum=momentum, inverting_grad=int(inverting_grad), decay_v=decay_v,
+                              ewc=ewc, ewc_decay=ewc_decay, ewc_fisher_beta=ewc_fisher_beta,
+                              ewc_for_critic=ewc_for_critic, ewc_best_param_method=ewc_best_method)
+    pop = ddrl_amd.DdpgPopulation(cfg, init_seed=seed)
+    if sweep:   # per-agent hyper-parameters drawn log-uniformly
+        alpha_a = 10 ** rng.uniform(-5, -2, G); alpha_v = 10 ** rng.uniform(-5, -2, G)
+        tau = 10 ** rng.uniform(-4, -1, G); gamma = rng.uniform(0.9, 0.999, G)
+    else:
+        alpha_a = np.full(G, 1e-4); alpha_v = np.full(G, 1e-3); tau = np.full(G, 1e-3); gamma = np.full(G, 0.99)
+    pop.set_hyper("alpha_a", alpha_a); pop.set_hyper("alpha_v", alpha_v)
+    pop.set_hyper("tau_soft_update", tau); pop.set_hyper("gamma", gamma)
+    seeds = (3000 + np.arange(G)).astype(np.uint32)
+    pop.seed_replay(seeds)
+    agents = []
+    na, nq = pop.num_params(0), pop.num_params(1)
+    wa = rng.normal(0, wscale, (G, na)); wq = rng.normal(0, wscale, (G, nq))
+    # the device holds fp32: give the oracle the fp32-rounded values so both start identical
+    wa = wa.astype(np.float32).astype(np.float64); wq = wq.astype(np.float32).astype(np.float64)
+    for net, w in ((0, wa), (1, wq), (2, wa), (3, wq)):
+        pop.set_weights(net, w)
+    for g in range(G):
+        ag = ora.Ddpg(S, A, B, hidden_a, hidden_q, replay_cap=replay_cap, hidden_act=hidden_act,
+                      actor_out_act=actor_out_act, momentum=momentum, inverting_grad=inverting_grad,
+                      gamma=float(np.float32(gamma[g])), tau=float(np.float32(tau[g])),
+                      alpha_a=float(np.float32(alpha_a[g])), alpha_v=float(np.float32(alpha_v[g])),
+                      decay_v=decay_v, ewc=ewc, ewc_decay=ewc_decay, ewc_fisher_beta=ewc_fisher_beta,
+                      ewc_for_critic=ewc_for_critic, ewc_best_method=ewc_best_method, seed=int(seeds[g]))
+        ag.ann.set_weights(wa[g]); ag.ann_target.set_weights(wa[g])
+        ag.qnn.set_weights(wq[g]); ag.qnn_target.set_weights(wq[g])
+        rows = synth_transitions(np.random.RandomState(1000 + g + 97 * seed), n_replay, S, A)
+        pop.replay_load(g, rows)
+        for row in rows.astype(np.float64):
+            ag.insert(row[:S], row[S:S + A], row[2 * S + A], row[S + A:2 * S + A], row[2 * S + A + 1] != 0)
+        agents.append(ag)
+    return pop, agents
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| (norm-wise relative error)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def oracle_weights(agents, net):
+    return np.stack([ag.nets[net].weights() for ag in agents])

@@ -1,0 +1,98 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/ddrl_pop.h
+declares, reports errors instead of exiting, and refuses to run without a GPU (no CPU path)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "ddrl_pop.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddrl_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ddrl_amd
+    from ddrl_amd import lib
+    L = ddrl_amd.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(s[0] for s in lib.SYMBOLS) == names
+
+
+def test_config_defaults_and_ini(tmp_path):
+    import ddrl_amd
+    c = ddrl_amd.DdpgConfig()
+    assert c.get("hidden_unit_a") == [100, 100] and c.get("mini_batch_size") == 64 and c.get("gamma") == 0.99
+    ini = tmp_path / "ddpg.ini"
+    ini.write_text("""
+[simulation]
+max_episode=100
+[agent]
+gamma=0.95
+decision_each=1
+; list syntax of bib::to_array
+hidden_unit_q=50:7
+hidden_unit_a=20
+noise=0.1
+gaussian_policy=1
+mini_batch_size=32
+replay_memory=5000
+inverting_grad=true
+force_more_update=7
+tau_soft_update=0.01
+alpha_a=0.0001
+alpha_v=0.001
+decay_v=-1
+batch_norm_critic=0
+batch_norm_actor=0
+actor_output_layer_type=2
+hidden_layer_type=1
+test_net=false
+bn_adapt=false
+momentum=0
+nstep_return=0
+[devnn]
+ewc=50
+ewc_decay=0.99
+ewc_fisher_beta=0.999
+ewc_best_param_method=0
+ewc_for_critic=1
+""")
+    c = ddrl_amd.DdpgConfig.from_ini(str(ini), n_agents=4, nb_sensors=4, nb_motors=1)
+    assert c.get("hidden_unit_q") == [50, 7] and c.get("hidden_unit_a") == [20]
+    assert c.get("gamma") == 0.95 and c.get("mini_batch_size") == 32 and c.get("inverting_grad") == 1
+    assert c.get("force_more_update") == 7 and c.get("ewc") == 50 and c.get("ewc_for_critic") == 1
+    assert c.get("n_agents") == 4 and c.get("nb_sensors") == 4
+    # a missing mandatory key is an error, as ptree::get throws in the reference (DeepQNAg.hpp:168-187)
+    bad = tmp_path / "bad.ini"
+    bad.write_text("[agent]\ngamma=0.9\n")
+    with pytest.raises(ddrl_amd.DdrlError) as e:
+        ddrl_amd.DdpgConfig.from_ini(str(bad))
+    assert "hidden_unit_q" in str(e.value)
+    with pytest.raises(ddrl_amd.DdrlError):
+        ddrl_amd.DdpgConfig.from_ini(str(tmp_path / "nope.ini"))
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ddrl_amd
+    with pytest.raises(ddrl_amd.DdrlError) as e:
+        ddrl_amd.DdpgPopulation(ddrl_amd.DdpgConfig(n_agents=2))
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under ddrl_amd/ may reference it."""
+    for dp, _, fns in os.walk(os.path.join(ROOT, "ddrl_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert "oracle" not in txt.replace("no CPU path", ""), os.path.join(dp, fn)
