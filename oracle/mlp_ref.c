@@ -381,3 +381,12 @@ void ora_mlp_get_ewc(const ora_mlp *n, double *fisher, double *fisher_hat, doubl
   if (fisher_nbr) *fisher_nbr = n->fisher ? n->fisher_nbr : 0.;
   if (decay_mult) *decay_mult = n->ewc_decay_mult;
 }
+
+/* test hook: overwrite previous_fisher / best_param_previous_task (re-synchronisation to the
+ * device's fp32 values in the teacher-forced parity tests) */
+void ora_mlp_set_ewc(ora_mlp *n, const double *fisher_hat, const double *wstar) {
+  if (!n->prev_fisher) n->prev_fisher = (double *)calloc(n->np, sizeof(double));
+  if (!n->best_prev) n->best_prev = (double *)calloc(n->np, sizeof(double));
+  memcpy(n->prev_fisher, fisher_hat, sizeof(double) * n->np);
+  memcpy(n->best_prev, wstar, sizeof(double) * n->np);
+}

@@ -66,6 +66,7 @@ void   ora_mlp_update_best_param(ora_mlp *n, double score);
 void   ora_mlp_get_ewc(const ora_mlp *n, double *fisher, double *fisher_hat, double *wstar,
                        double *fisher_nbr, double *decay_mult);
 int    ora_mlp_ewc_active(const ora_mlp *n);
+void   ora_mlp_set_ewc(ora_mlp *n, const double *fisher_hat, const double *wstar);
 
 /* ---- DDPG (ddpg_ref.c) ---- */
 typedef struct ora_ddpg ora_ddpg;

@@ -96,6 +96,7 @@ def lib():
     L.ora_mlp_update_best_param.argtypes = [vp, C.c_double]
     L.ora_mlp_get_ewc.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ora_mlp_ewc_active.argtypes = [vp]
+    L.ora_mlp_set_ewc.argtypes = [vp, vp, vp]
     L.ora_mt_seed.argtypes = [vp, C.c_uint32]
     L.ora_mt_next.restype = C.c_uint32
     L.ora_mt_next.argtypes = [vp]

@@ -68,3 +68,76 @@ def rel_err(a, b):
 
 def oracle_weights(agents, net):
     return np.stack([ag.nets[net].weights() for ag in agents])
+
+
+# ---------------------------------------------------------------------------------------------
+# Parity bar for the weights (see DESIGN.md "Parity bar").
+#
+# Caffe's Adam with momentum=0 (beta1 = 0, MLP.hpp:160-162) applies lr_t * g / (sqrt(v) + eps): at
+# small t this is ~ lr * sign(g), discontinuous at g = 0.  A gradient that is itself within fp32
+# rounding of zero therefore moves its weight by up to 2*lr differently in fp32 and fp64, and the
+# iteration is chaotic from there on: "weights after N free-running updates within 1e-5" is not a
+# property any fp32 implementation can have.  What IS well-conditioned, and is asserted:
+#   (1) per update, from identical state (the oracle is re-synchronised to the device's fp32 state
+#       before each step): TD targets, loss, action gradients, the gradients themselves (Adam m, v)
+#       agree to 1e-5 norm-wise;
+#   (2) the device's new weights equal  w_prev - lr_t * m / (sqrt(v) + eps)  evaluated in fp64 from
+#       the device's own m, v to 1e-5 (the optimiser arithmetic is right);
+#   (3) the directly compared weights agree to 1e-5 on >= 99.9 % of the parameters, and nowhere
+#       differ by more than Adam's step bound 2 * lr_t.
+# ---------------------------------------------------------------------------------------------
+BETAS = {0: (0.0, 0.999), 1: (0.9, 0.999), 2: (0.0, 0.0), 3: (0.9, 0.0)}
+
+
+def sync_oracle_from_gpu(pop, agents):
+    ws = [pop.weights(n) for n in range(4)]
+    ad = [pop.adam(n) for n in (0, 1)]
+    for g, ag in enumerate(agents):
+        for n in range(4):
+            ag.nets[n].set_weights(ws[n][g])
+        for n in (0, 1):
+            ag.nets[n].set_adam(ad[n][0][g], ad[n][1][g], int(ad[n][2][g]))
+    return ws, ad
+
+
+def check_step(pop, agents, ws_prev, lrs, momentum, tol=1e-5, frac=0.999, allow_kink=False):
+    """Asserts (1)-(3) above after one update on both sides. lrs = (alpha_a[G], alpha_v[G])."""
+    b1, b2 = BETAS[momentum]
+    out = {}
+    for net in (0, 1):
+        m, v, it = pop.adam(net)
+        mo = np.stack([ag.nets[net].adam()[0] for ag in agents])
+        vo = np.stack([ag.nets[net].adam()[1] for ag in agents])
+        for g in range(len(agents)):
+            # allow_kink: a ReLU unit whose pre-activation is within fp32 rounding of 0 may switch
+            # branch between fp32 and fp64 and move a few gradient entries (see close_frac)
+            assert rel_err(m[g], mo[g]) <= tol or (allow_kink and close_frac(m[g], mo[g], tol)), ("m", net, g, rel_err(m[g], mo[g]))
+            assert rel_err(v[g], vo[g]) <= 2 * tol or (allow_kink and close_frac(v[g], vo[g], 2 * tol)), ("v", net, g, rel_err(v[g], vo[g]))
+        w = pop.weights(net)
+        wo = oracle_weights(agents, net)
+        for g in range(len(agents)):
+            t = int(it[g])
+            lr_t = float(np.float32(lrs[net][g])) * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            expect = ws_prev[net][g] - lr_t * m[g] / (np.sqrt(v[g]) + 1e-8)
+            wmax = np.max(np.abs(wo[g]))
+            assert np.max(np.abs(w[g] - expect)) <= tol * wmax, ("adam-consistency", net, g)
+            err = np.abs(w[g] - wo[g])
+            assert np.mean(err <= tol * wmax) >= frac, ("weights", net, g, np.mean(err <= tol * wmax))
+            assert np.max(err) <= 2 * lr_t * 1.001 + tol * wmax, ("step bound", net, g, np.max(err))
+        out[net] = rel_err(w, wo)
+    for net in (2, 3):   # targets: tau * (w error) -- always well inside the bar
+        w = pop.weights(net); wo = oracle_weights(agents, net)
+        for g in range(len(agents)):
+            wmax = np.max(np.abs(wo[g]))
+            assert np.mean(np.abs(w[g] - wo[g]) <= tol * wmax) >= frac, ("target", net, g)
+    return out
+
+
+def close_frac(a, b, tol=1e-5, frac=0.999, cap=1e-3):
+    """>= frac of the elements within tol * max|b|, none beyond cap * max|b|.  Used where a hard
+    ReLU / leaky-ReLU kink (a pre-activation within fp32 rounding of 0 takes the other branch in
+    fp64) can legitimately move a few gradient entries."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = max(np.max(np.abs(b)), 1e-300)
+    err = np.abs(a - b) / scale
+    return bool(np.mean(err <= tol) >= frac and np.max(err) <= cap)
