@@ -70,6 +70,10 @@ struct ddrl_pop {
   uint8_t *d_goal = nullptr, *d_mask = nullptr, *d_flag = nullptr;
   std::vector<void *> allocs;
   DdpgParams P;
+  // measurement
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
 };
 
 #define HIPCHK(expr)                                                                        \
@@ -398,6 +402,7 @@ extern "C" int ddrl_pop_destroy(ddrl_pop_t *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : h->allocs) (void)hipFree(p);
+  for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return DDRL_OK;
@@ -583,7 +588,19 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
   h->P.mask = dmask;
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling) {
+    if (h->ev_used == h->ev_pool.size()) {
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      h->ev_pool.emplace_back(e0, e1);
+    }
+    e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second;
+    h->ev_used++;
+    HIPCHK(hipEventRecord(e0, h->stream));
+  }
   HIPCHK(ddpg_update_launch(&h->P, h->stream));
+  if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
 }
@@ -709,5 +726,29 @@ extern "C" int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *
     for (int g = 0; g < h->G; ++g) fisher_nbr[g] = f[g];
   }
   if (decay_mult) for (int g = 0; g < h->G; ++g) decay_mult[g] = t.ewc.decay_mult[g];
+  return DDRL_OK;
+}
+
+// ---- measurement hooks ----
+extern "C" int ddrl_pop_set_profiling(ddrl_pop_t *h, int on) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  h->profiling = on != 0;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_profile_read(ddrl_pop_t *h, double *kernel_ms, int *launches) {
+  if (!h || !kernel_ms || !launches) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double tot = 0.;
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+    tot += ms;
+  }
+  *kernel_ms = tot;
+  *launches = (int)h->ev_used;
+  h->ev_used = 0;
   return DDRL_OK;
 }

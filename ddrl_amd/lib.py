@@ -64,6 +64,8 @@ SYMBOLS = [
     ("ddrl_pop_ewc_decay_update", _i, [_vp, _vp]),
     ("ddrl_pop_ewc_cost", _i, [_vp, _i, _vp]),
     ("ddrl_pop_get_ewc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_pop_set_profiling", _i, [_vp, _i]),
+    ("ddrl_pop_profile_read", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
 ]
 
 _lib = None

@@ -171,3 +171,12 @@ class DdpgPopulation:
         nbr, dm = np.empty(self.G), np.empty(self.G)
         _l.check(self.L.ddrl_pop_get_ewc(self.h, net, _p(f), _p(fh), _p(ws), _p(nbr), _p(dm)))
         return dict(fisher=f, fisher_hat=fh, wstar=ws, fisher_nbr=nbr, decay_mult=dm)
+
+    def set_profiling(self, on=True):
+        _l.check(self.L.ddrl_pop_set_profiling(self.h, int(on)))
+
+    def profile_read(self):
+        """(summed update-kernel milliseconds, launches) since the last read; synchronises."""
+        ms, n = C.c_double(), C.c_int()
+        _l.check(self.L.ddrl_pop_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

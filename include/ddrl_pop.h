@@ -137,6 +137,13 @@ int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost /* [G] */);
 int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat, double *wstar,
                      double *fisher_nbr /* [G] */, double *decay_mult /* [G] */);
 
+/* Measurement hooks (no counterpart in the reference, which only records total wall minutes,
+ * common/include/arch/Simulator.hpp:127): with profiling on, every ddrl_pop_ddpg_update() brackets
+ * its update kernel with HIP events on the handle's stream; ddrl_pop_profile_read() synchronises and
+ * returns the summed kernel time and the number of launches since the last read. */
+int ddrl_pop_set_profiling(ddrl_pop_t *h, int on);
+int ddrl_pop_profile_read(ddrl_pop_t *h, double *kernel_ms, int *launches);
+
 #ifdef __cplusplus
 }
 #endif
