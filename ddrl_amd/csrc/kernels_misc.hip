@@ -19,14 +19,26 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
+// The same launch prepares the update's Adam step sizes: caffe AdamSolver uses t = iter + 1 and
+// correction = sqrt(1 - beta2^t) / (1 - beta1^t); evaluated in fp64 because 1 - 0.999^t loses 4
+// digits in fp32 at small t.  draw == 0: indices come from the host, only the step sizes are made.
 extern "C" __global__ void __launch_bounds__(64)
 replay_draw_kernel(uint32_t *__restrict__ mt, int *__restrict__ pos, const int *__restrict__ rep_len,
-                   int B, int min_len, const uint8_t *__restrict__ mask, int *__restrict__ idx_out) {
+                   int B, int min_len, const uint8_t *__restrict__ mask, int *__restrict__ idx_out, int draw,
+                   double beta1, double beta2, const float *__restrict__ lr_a, const float *__restrict__ lr_q,
+                   const int *__restrict__ iter_a, const int *__restrict__ iter_q,
+                   float *__restrict__ lrt_a, float *__restrict__ lrt_q) {
   __shared__ uint32_t st[624];
   const int agent = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[agent]) return;
   const uint32_t n = (uint32_t)rep_len[agent];
   if ((int)n < min_len || (int)n < B) return;       // the guard of DeepQNAg.hpp:338: no draw consumed
+  if (lane < 2) {
+    const int t = (lane ? iter_q : iter_a)[agent] + 1;
+    const double corr = sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+    (lane ? lrt_q : lrt_a)[agent] = (float)((double)(lane ? lr_q : lr_a)[agent] * corr);
+  }
+  if (!draw) return;
   uint32_t *gst = mt + (size_t)agent * 624;
   for (int i = lane; i < 624; i += 64) st[i] = gst[i];
   int p = pos[agent];
@@ -122,23 +134,23 @@ infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restr
              float *__restrict__ actions, const float *__restrict__ in_gate, const float *__restrict__ out_gate) {
   __shared__ __align__(16) float buf[2][DDRL_MAXW + 8];
   const int agent = blockIdx.x, lane = threadIdx.x;
-  const float *wa = w + (size_t)agent * nd.stride;
-  const int d0 = nd.d[0];
-  for (int k = lane; k < nd.kp[0]; k += 64) {
+  const float *wa = w + (size_t)agent * nd.stride();
+  const int d0 = nd.d(0);
+  for (int k = lane; k < nd.kp(0); k += 64) {
     float x = k < d0 ? states[(size_t)agent * d0 + k] : 0.f;
     if (in_gate && k < d0) x *= in_gate[(size_t)agent * d0 + k];
     buf[0][k] = x;
   }
   __syncthreads();
   int cur = 0;
-  for (int l = 0; l < nd.L; ++l) {
-    const int kp = nd.kp[l], N = nd.d[l + 1];
-    const bool last = l == nd.L - 1;
-    const int act = last ? nd.out_act : nd.hidden_act;
+  for (int l = 0; l < nd.L(); ++l) {
+    const int kp = nd.kp(l), N = nd.d(l + 1);
+    const bool last = l == nd.L() - 1;
+    const int act = last ? nd.out_act() : nd.hidden_act();
     for (int n = lane; n < ddrl_roundup(N, 4); n += 64) {
       float y = 0.f;
       if (n < N) {
-        const float *row = wa + nd.offw[l] + (size_t)n * kp;
+        const float *row = wa + nd.offw(l) + (size_t)n * kp;
         float s = 0.f;
         for (int k = 0; k < kp; k += 4) {
           const f32x4 wv = *(const f32x4 *)(row + k);
@@ -146,7 +158,7 @@ infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restr
           s = fmaf(wv[0], xv[0], s); s = fmaf(wv[1], xv[1], s);
           s = fmaf(wv[2], xv[2], s); s = fmaf(wv[3], xv[3], s);
         }
-        y = act_fwd(act, s + wa[nd.offb[l] + n]);
+        y = act_fwd(act, s + wa[nd.offb(l) + n]);
       }
       if (last) {
         if (n < N) {
@@ -225,8 +237,11 @@ ewc_cost_kernel(const float *__restrict__ w, const float *__restrict__ wstar, co
 
 // ---- launch wrappers (called from the host side in pop.hip) ----
 extern "C" hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B,
-                                         const uint8_t *mask, int *idx_out, hipStream_t st) {
-  hipLaunchKernelGGL(replay_draw_kernel, dim3(G), dim3(64), 0, st, mt, pos, rep_len, B, 250, mask, idx_out);
+                                         const uint8_t *mask, int *idx_out, int draw, double beta1, double beta2,
+                                         const float *lr_a, const float *lr_q, const int *iter_a, const int *iter_q,
+                                         float *lrt_a, float *lrt_q, hipStream_t st) {
+  hipLaunchKernelGGL(replay_draw_kernel, dim3(G), dim3(64), 0, st, mt, pos, rep_len, B, 250, mask, idx_out, draw,
+                     beta1, beta2, lr_a, lr_q, iter_a, iter_q, lrt_a, lrt_q);
   return hipGetLastError();
 }
 extern "C" hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, hipStream_t st) {

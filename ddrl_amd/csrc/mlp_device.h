@@ -7,6 +7,10 @@
 // bit-for-bit an fp32 fma chain (cdna_hip_programming.md section 3), so results do not depend on
 // tile shapes beyond the order of the k-sum.
 //
+// Every function takes the layer shape as plain ints.  Called from a kernel instantiated on a
+// compile-time net (SNet<...>) they arrive as constants and all guards / loop bounds fold; called
+// from the generic kernel (NetDesc) the same source handles any shape up to DDRL_MAXW.
+//
 // Lane roles for v_mfma_f32_16x16x4_f32 (lane l, c = l & 15, g = l >> 4):
 //   A operand: A[i = c][kk = g]     B operand: B[kk = g][j = c]     D reg r: D[i = 4g + r][j = c]
 // A 16-deep k-chunk is issued as 4 MFMAs; in MFMA jj the kk slot g carries k = k0 + 4g + jj, so
@@ -17,6 +21,7 @@
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
 // Caffe ReLULayer (negative_slope 0.01 for hidden_layer_type 1, MLP.hpp:888-897), TanHLayer
 __device__ __forceinline__ float act_fwd(int t, float x) {
@@ -37,51 +42,100 @@ __device__ __forceinline__ float act_bwd(int t, float y, float dy) {
   }
 }
 
-// Y[64 x N] = act(X[64 x K] W^T + b).  Xs: LDS, row stride ldx, columns [K, kp) hold zeros.
-// W: global, [N x kp] row-major.  Ys: LDS, row stride ldy; columns [N, roundup(N,4)) are zeroed.
-// Wave w owns output column tiles nt = w, w+4, ... and all four row tiles, so W is read once.
-__device__ __forceinline__ void fwd_layer(const float *__restrict__ Xs, int ldx, int kp,
-                                          const float *__restrict__ W, const float *__restrict__ bias,
-                                          int N, int act, float *__restrict__ Ys, int ldy,
-                                          int wave, int lane) {
+// The weight fragments one lane feeds to the MFMAs of one 16-column output tile: row n = nt*16 + c
+// of W, columns kc*16 + 4g .. + 3 for every 16-deep k-chunk kc.  Requested in one burst so the
+// L2/HBM latency is paid once per tile; callers request the NEXT tile's fragments (also across a
+// layer boundary: weights do not depend on activations) before computing the current one.
+struct BFrag { f32x4 v[DDRL_MAXKC]; };
+
+__device__ __forceinline__ void load_bfrag(const float *__restrict__ W, int kp, int N, int nt, int lane, BFrag &b) {
   const int g = lane >> 4, c = lane & 15;
-  const int NT = (N + 15) >> 4;
-  for (int nt = wave; nt < NT; nt += DDRL_NWAVES) {
-    f32x4 acc[4];
+  const int n = nt * 16 + c;
+  const float *wrow = W + (size_t)(n < N ? n : N - 1) * kp;
+  // no divergent branch around a load: the address is clamped into the row and the value masked
+  // afterwards, so the compiler can count the outstanding loads exactly (a load inside a lane-
+  // dependent branch makes it fall back to s_waitcnt vmcnt(0) at the join)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int n = nt * 16 + c;
-    const float *wrow = W + (size_t)(n < N ? n : N - 1) * kp;
-    for (int k0 = 0; k0 < kp; k0 += 16) {
-      const int k = k0 + 4 * g;
-      const bool in = k < kp;
-      f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (in) b = *(const f32x4 *)(wrow + k);
+  for (int kc = 0; kc < DDRL_MAXKC; ++kc) {
+    if (kc * 16 < kp) {                       // uniform (folds for compile-time shapes)
+      const int k = kc * 16 + 4 * g;
+      const f32x4 v = *(const f32x4 *)(wrow + (k < kp ? k : kp - 4));
+      b.v[kc] = (kc * 16 + 16 <= kp || k < kp) ? v : zero4();
+    }
+  }
+}
+
+// One 64 x 16 output tile of Y = act(X W^T + b).  Xs: LDS, row stride ldx, columns [K, kp) hold
+// zeros.  Ys: LDS, row stride ldy; columns [N, roundup(N,4)) are zeroed.
+__device__ __forceinline__ void fwd_tile(const float *__restrict__ Xs, int ldx, int kp, const BFrag &b,
+                                         const float *__restrict__ bias, int N, int act,
+                                         float *__restrict__ Ys, int ldy, int nt, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  const int n = nt * 16 + c;
+  const float bv = bias[n < N ? n : N - 1];
+  f32x4 acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc[mt] = zero4();
+#pragma unroll
+  for (int kc = 0; kc < DDRL_MAXKC; ++kc) {
+    if (kc * 16 < kp) {
+      // columns >= kp of this chunk meet zero weight fragments: read a clamped (valid, finite) column
+      const int k = kc * 16 + 4 * g < kp ? kc * 16 + 4 * g : kp - 4;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (in) a = *(const f32x4 *)(Xs + (mt * 16 + c) * ldx + k);
-        acc[mt] = mfma16(a[0], b[0], acc[mt]);
-        acc[mt] = mfma16(a[1], b[1], acc[mt]);
-        acc[mt] = mfma16(a[2], b[2], acc[mt]);
-        acc[mt] = mfma16(a[3], b[3], acc[mt]);
+        const f32x4 a = *(const f32x4 *)(Xs + (mt * 16 + c) * ldx + k);
+        acc[mt] = mfma16(a[0], b.v[kc][0], acc[mt]);
+        acc[mt] = mfma16(a[1], b.v[kc][1], acc[mt]);
+        acc[mt] = mfma16(a[2], b.v[kc][2], acc[mt]);
+        acc[mt] = mfma16(a[3], b.v[kc][3], acc[mt]);
       }
     }
-    const float bv = n < N ? bias[n] : 0.f;
+  }
+  if (n < ldy) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + 4 * g + r;
-        if (n < N) Ys[row * ldy + n] = act_fwd(act, acc[mt][r] + bv);
-        else if (n < ldy) Ys[row * ldy + n] = 0.f;
+        Ys[row * ldy + n] = n < N ? act_fwd(act, acc[mt][r] + bv) : 0.f;
       }
   }
 }
 
+// Y[64 x N] = act(X W^T + b) for one layer, wave w owning column tiles w, w+NWAVES, ... (all four row
+// tiles each, so W is read once).  have/b0: fragments of this wave's first tile if already
+// requested by the caller.  nextW != null: once the last tile's fragments are in flight, request
+// the first tile of the next layer (returned in b0 with have = true).
+__device__ __forceinline__ void fwd_layer(const float *__restrict__ Xs, int ldx, int kp,
+                                          const float *__restrict__ W, const float *__restrict__ bias,
+                                          int N, int act, float *__restrict__ Ys, int ldy,
+                                          int wave, int lane, BFrag &b0, bool &have,
+                                          const float *__restrict__ nextW, int next_kp, int nextN) {
+  const int NT = (N + 15) >> 4;
+  if (!have && wave < NT) load_bfrag(W, kp, N, wave, lane, b0);
+  have = false;
+  const bool next_mine = nextW && wave < ((nextN + 15) >> 4);
+  // two fragment sets with static names (a register copy would wait for the loads it copies)
+  BFrag b1;
+  for (int nt = wave; nt < NT; nt += 2 * DDRL_NWAVES) {
+    const int nt1 = nt + DDRL_NWAVES, nt2 = nt1 + DDRL_NWAVES;
+    if (nt1 < NT) load_bfrag(W, kp, N, nt1, lane, b1);
+    else if (next_mine) load_bfrag(nextW, next_kp, nextN, wave, lane, b1);
+    fwd_tile(Xs, ldx, kp, b0, bias, N, act, Ys, ldy, nt, lane);
+    if (nt1 < NT) {
+      if (nt2 < NT) load_bfrag(W, kp, N, nt2, lane, b0);
+      else if (next_mine) { load_bfrag(nextW, next_kp, nextN, wave, lane, b0); have = true; }
+      fwd_tile(Xs, ldx, kp, b1, bias, N, act, Ys, ldy, nt1, lane);
+    } else if (next_mine) {
+      b0 = b1;       // odd tile count: the next layer's fragments landed in b1
+      have = true;
+    }
+  }
+}
+
 // dX[64 x cols] = dY[64 x N] W[N x kp], for column tiles kt in [kt0, kt1); wave w owns tiles
-// kt0 + w + 4 i, i < MAXKT, results stay in registers (acc[i][mt]).  dYs: LDS, columns [N, roundup
-// (N,4)) must hold zeros.
+// kt0 + w + NWAVES i, i < MAXKT, results stay in registers (acc[i][mt]).  dYs: LDS, columns [N, roundup
+// (N,4)) must hold zeros.  The weight fragments of a tile are requested in one burst.
 template <int MAXKT>
 __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, int N,
                                        const float *__restrict__ W, int kp, int kt0, int kt1,
@@ -91,24 +145,35 @@ __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, i
 #pragma unroll
   for (int i = 0; i < MAXKT; ++i) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 4; ++mt) acc[i][mt] = zero4();
     const int kt = kt0 + wave + DDRL_NWAVES * i;
     if (kt < kt1) {
       const int col = kt * 16 + c;
-      const bool cin = col < kp;
-      for (int n0 = 0; n0 < N; n0 += 16) {
-        const int nn = n0 + 4 * g;
-        float b[4];
+      const int colc = col < kp ? col : kp - 1;        // clamp: columns >= kp are discarded
+      float b[DDRL_MAXKC][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = (cin && nn + j < N) ? W[(size_t)(nn + j) * kp + col] : 0.f;
+      for (int nc = 0; nc < DDRL_MAXKC; ++nc)
+        if (nc * 16 < N) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (nn < n4) a = *(const f32x4 *)(dYs + (mt * 16 + c) * ldy + nn);
-          acc[i][mt] = mfma16(a[0], b[0], acc[i][mt]);
-          acc[i][mt] = mfma16(a[1], b[1], acc[i][mt]);
-          acc[i][mt] = mfma16(a[2], b[2], acc[i][mt]);
-          acc[i][mt] = mfma16(a[3], b[3], acc[i][mt]);
+          for (int j = 0; j < 4; ++j) {
+            const int nn = nc * 16 + 4 * g + j;
+            const float v = W[(size_t)(nn < N ? nn : N - 1) * kp + colc];     // clamped, then masked
+            b[nc][j] = (nc * 16 + 16 <= N || nn < N) ? v : 0.f;
+          }
+        }
+#pragma unroll
+      for (int nc = 0; nc < DDRL_MAXKC; ++nc) {
+        if (nc * 16 < N) {
+          // dY columns >= roundup(N,4) meet zero weights: read a clamped (valid, finite) column
+          const int nn = nc * 16 + 4 * g < n4 ? nc * 16 + 4 * g : n4 - 4;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 a = *(const f32x4 *)(dYs + (mt * 16 + c) * ldy + nn);
+            acc[i][mt] = mfma16(a[0], b[nc][0], acc[i][mt]);
+            acc[i][mt] = mfma16(a[1], b[nc][1], acc[i][mt]);
+            acc[i][mt] = mfma16(a[2], b[nc][2], acc[i][mt]);
+            acc[i][mt] = mfma16(a[3], b[nc][3], acc[i][mt]);
+          }
         }
       }
     }
@@ -124,59 +189,152 @@ struct OptCtx {
   float beta1, beta2, omb1, omb2, eps;
 };
 
-// One parameter: Fisher EMA (DODevMLP.hpp:651), EWC penalty (DODevMLP.hpp:702), L2 decay
-// (caffe SGDSolver::Regularize), Adam (caffe AdamSolver::ComputeUpdateValue + Net::Update) and the
-// target net's soft update (MLP.hpp:449-450) in a single read-modify-write of each array.
-__device__ __forceinline__ void opt_step(const OptCtx &o, int i, float grad) {
+// Optimiser state of 4 consecutive parameters, requested before the products that produce their
+// gradient so the HBM latency hides behind the MFMAs.
+struct OptRegs { f32x4 w, m, v, wt, fisher, fhat, wstar; };
+
+// EWC: the net has Fisher / anchor arrays (DODevMLP.hpp:604-707).  TGT: the net has a target twin
+// that is soft-updated in the same pass (MLP.hpp:437-452).
+template <bool EWC, bool TGT>
+__device__ __forceinline__ void opt_load4(const OptCtx o, int i, OptRegs &r) {
+#ifdef DDRL_EXP_NOOPTMEM
+  r.w = r.m = r.v = r.wt = r.fisher = r.fhat = r.wstar = (f32x4){(float)i, 1.f, 2.f, 3.f};
+  return;
+#endif
+  r.w = *(const f32x4 *)(o.w + i);
+  r.m = *(const f32x4 *)(o.m + i);
+  r.v = *(const f32x4 *)(o.v + i);
+  if (TGT) r.wt = *(const f32x4 *)(o.wt + i);
+  if (EWC) {
+    r.fisher = *(const f32x4 *)(o.fisher + i);
+    r.fhat = *(const f32x4 *)(o.fhat + i);
+    r.wstar = *(const f32x4 *)(o.wstar + i);
+  }
+}
+
+// Four parameters: Fisher EMA (DODevMLP.hpp:651), EWC penalty (DODevMLP.hpp:702; ewc_coef is 0 and
+// fhat / wstar are all-zero until the first ewc_setup), L2 decay (caffe SGDSolver::Regularize; decay
+// <= 0 = off), Adam (caffe AdamSolver::ComputeUpdateValue + Net::Update) and the target net's soft
+// update (MLP.hpp:449-450): one read and one write of each array per update, no branches.
+template <bool EWC, bool TGT>
+__device__ __forceinline__ void opt_step4(const OptCtx o, int i, f32x4 grad, const OptRegs &r, bool ok) {
+  f32x4 w = r.w, m, v, f, wt;
+  if (EWC) {
+    f = r.fisher * o.fisher_beta + (grad * grad) * o.nsample;
+    grad += o.ewc_coef * r.fhat * (w - r.wstar);
+  }
+  grad += fmaxf(o.decay, 0.f) * w;
+  m = o.omb1 * grad + o.beta1 * r.m;
+  v = o.omb2 * (grad * grad) + o.beta2 * r.v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] -= o.lr_t * (m[e] / (sqrtf(v[e]) + o.eps));
+  if (TGT) wt = o.tau * w + o.omtau * r.wt;
+#ifdef DDRL_EXP_NOOPTMEM
+  ok = ok && (w[0] + wt[1] + m[2] + v[3] + (EWC ? f[0] : 0.f) == 12345.678f);
+#endif
+  if (ok) {                                   // stores only: nothing waits on them
+    if (EWC) *(f32x4 *)(o.fisher + i) = f;
+    *(f32x4 *)(o.m + i) = m;
+    *(f32x4 *)(o.v + i) = v;
+    *(f32x4 *)(o.w + i) = w;
+    if (TGT) *(f32x4 *)(o.wt + i) = wt;
+  }
+}
+
+// scalar form (biases)
+template <bool EWC, bool TGT>
+__device__ __forceinline__ void opt_step(const OptCtx o, int i, float grad) {
   float w = o.w[i];
-  if (o.fisher) o.fisher[i] = o.fisher[i] * o.fisher_beta + (grad * grad) * o.nsample;
-  if (o.ewc_coef != 0.f) grad += o.ewc_coef * o.fhat[i] * (w - o.wstar[i]);
-  if (o.decay > 0.f) grad += o.decay * w;
+  if (EWC) {
+    o.fisher[i] = o.fisher[i] * o.fisher_beta + (grad * grad) * o.nsample;
+    grad += o.ewc_coef * o.fhat[i] * (w - o.wstar[i]);
+  }
+  grad += fmaxf(o.decay, 0.f) * w;
   const float m = o.omb1 * grad + o.beta1 * o.m[i];
   const float v = o.omb2 * (grad * grad) + o.beta2 * o.v[i];
   o.m[i] = m;
   o.v[i] = v;
   w -= o.lr_t * (m / (sqrtf(v) + o.eps));
   o.w[i] = w;
-  if (o.wt) o.wt[i] = o.tau * w + o.omtau * o.wt[i];
+  if (TGT) o.wt[i] = o.tau * w + o.omtau * o.wt[i];
 }
 
-// dW[N x K] = dY^T X  (+ db = dY^T 1), each element handed to opt_step() straight from the MFMA
-// accumulator.  dYs [64 x N] and Xs [64 x K] in LDS; rows >= batch must be zero in dYs.
+// dW[N x K] = dY^T X  (+ db = dY^T 1), each element handed to the optimiser straight from the MFMA
+// accumulator.  The product is issued transposed (A = X, B = dY) so that lane (c, g) ends up with
+// dW[n = nt*16 + c][k = kt*16 + 4g .. + 3]: four consecutive parameters = one 16-byte access to
+// each state array.  dYs [64 x N] and Xs [64 x K] in LDS; rows >= batch must be zero in dYs.
 // Output tiles (nt, kt) are dealt to the waves in contiguous runs (balanced to within one tile).
+// Pad columns [K, kp) take part: their gradient is exactly 0 and their state stays 0.
+// element index of lane (c, g)'s 4 parameters in output tile p of a [N x kp] weight block; ok = the
+// lane owns real parameters there (else the index is clamped to a valid, aligned element whose
+// loaded state is ignored)
+__device__ __forceinline__ int dw_elem(int p, int total, int KT, int N, int kp, int offw, int c, int g, bool &ok) {
+  const int pc = p < total ? p : total - 1;
+  const int nt = pc / KT, kt = pc - nt * KT;
+  const int n = nt * 16 + c, k = kt * 16 + 4 * g;
+  ok = p < total && n < N && k < kp;
+  return ok ? offw + n * kp + k : offw;
+}
+
+// one 16 x 16 tile of dW^T = X^T dY (64-deep), result lane layout: see bwd_dw_opt
+__device__ __forceinline__ f32x4 dw_tile(const float *__restrict__ dYs, int ldy, int N,
+                                         const float *__restrict__ Xs, int ldx, int kp,
+                                         int p, int total, int KT, int c, int g) {
+  const int pc = p < total ? p : total - 1;
+  const int nt = pc / KT, kt = pc - nt * KT;
+  const int bn = nt * 16 + c, ak = kt * 16 + c;
+  // clamped operand columns: the products they feed land in elements that are never stored
+  const float *xa = Xs + (ak < kp ? ak : kp - 1) + 4 * g * ldx;
+  const float *yb = dYs + (bn < N ? bn : N - 1) + 4 * g * ldy;
+  f32x4 acc = zero4();
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = mc * 16 + j;
+      acc = mfma16(xa[row * ldx], yb[row * ldy], acc);
+    }
+  return acc;
+}
+
+template <bool EWC, bool TGT>
 __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ldy, int N,
-                                           const float *__restrict__ Xs, int ldx, int K, int kp,
-                                           int offw, int offb, const OptCtx &o,
+                                           const float *__restrict__ Xs, int ldx, int kp,
+                                           int offw, int offb, const OptCtx o,
                                            int wave, int lane, int tid) {
   const int g = lane >> 4, c = lane & 15;
-  const int NT = (N + 15) >> 4, KT = (K + 15) >> 4;
+  const int NT = (N + 15) >> 4, KT = (kp + 15) >> 4;
   const int total = NT * KT;
-  const int per = (total + DDRL_NWAVES - 1) / DDRL_NWAVES;
-  const int p1 = min(total, (wave + 1) * per);
-  for (int p = wave * per; p < p1; ++p) {
-    const int nt = p / KT, kt = p - nt * KT;
-    const int an = nt * 16 + c, bk = kt * 16 + c;
-    const bool ain = an < N, bin = bk < K;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mc = 0; mc < 4; ++mc)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = mc * 16 + 4 * g + j;
-        const float a = ain ? dYs[row * ldy + an] : 0.f;
-        const float b = bin ? Xs[row * ldx + bk] : 0.f;
-        acc = mfma16(a, b, acc);
-      }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nt * 16 + 4 * g + r;
-      if (n < N && bk < K) opt_step(o, offw + n * kp + bk, acc[r]);
+  const int per = (total + DDRL_NWAVES - 1) / DDRL_NWAVES;   // tile slots per wave, the same for every wave
+  const int p0 = wave * per;
+  // Two statically named state sets: the next tile's optimiser state is requested BEFORE this
+  // tile's stores are issued (vector memory operations retire in issue order, so a load queued
+  // behind the stores would wait for them) and is never copied (a copy would wait for the load).
+  // Every wave walks `per` slots and every lane loads in every slot (clamped addresses); only the
+  // stores are predicated.  The two-tile body is kept as a real loop (unrolling it
+  // fully makes the scheduler hoist every tile's loads and spill); inside it the outstanding
+  // loads are counted exactly (s_waitcnt vmcnt(N), not 0).
+  OptRegs r0, r1;
+  bool ok0 = false, ok1 = false;
+  int i0 = dw_elem(p0, total, KT, N, kp, offw, c, g, ok0), i1 = 0;
+  opt_load4<EWC, TGT>(o, i0, r0);
+#pragma unroll 1
+  for (int s = 0; s < per; s += 2) {
+    if (s + 1 < per) { i1 = dw_elem(p0 + s + 1, total, KT, N, kp, offw, c, g, ok1); opt_load4<EWC, TGT>(o, i1, r1); }
+    {
+      const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
+      opt_step4<EWC, TGT>(o, i0, acc, r0, ok0);
+    }
+    if (s + 1 < per) {
+      if (s + 2 < per) { i0 = dw_elem(p0 + s + 2, total, KT, N, kp, offw, c, g, ok0); opt_load4<EWC, TGT>(o, i0, r0); }
+      const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s + 1, total, KT, c, g);
+      opt_step4<EWC, TGT>(o, i1, acc, r1, ok1);
     }
   }
   // bias gradient: column sums of dY, ascending row order
   for (int n = tid; n < N; n += DDRL_NTHREADS) {
     float s = 0.f;
     for (int row = 0; row < DDRL_MB; ++row) s += dYs[row * ldy + n];
-    opt_step(o, offb + n, s);
+    opt_step<EWC, TGT>(o, offb + n, s);
   }
 }

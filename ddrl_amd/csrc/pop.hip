@@ -15,10 +15,12 @@
 #include <vector>
 
 extern "C" {
-hipError_t ddpg_update_launch(const DdpgParams *P, hipStream_t st);
+hipError_t ddpg_update_launch(const DdpgParams *P, int force_generic, hipStream_t st);
 size_t ddpg_update_lds_bytes(const DdpgParams *P);
 hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B, const uint8_t *mask,
-                              int *idx_out, hipStream_t st);
+                              int *idx_out, int draw, double beta1, double beta2, const float *lr_a,
+                              const float *lr_q, const int *iter_a, const int *iter_q, float *lrt_a, float *lrt_q,
+                              hipStream_t st);
 hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, hipStream_t st);
 hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap, int rowlen, int S, int A,
                                 const float *s, const float *a, const float *r, const float *s2,
@@ -65,6 +67,7 @@ struct ddrl_pop {
   float *d_tau = nullptr, *d_omtau = nullptr, *d_gamma = nullptr;
   // diagnostics
   float *d_loss = nullptr, *d_qt = nullptr, *d_dact = nullptr;
+  long long *d_stamps = nullptr;
   // staging
   float *d_s = nullptr, *d_a = nullptr, *d_r = nullptr, *d_s2 = nullptr, *d_act = nullptr, *d_cost = nullptr;
   uint8_t *d_goal = nullptr, *d_mask = nullptr, *d_flag = nullptr;
@@ -72,6 +75,8 @@ struct ddrl_pop {
   DdpgParams P;
   // measurement
   bool profiling = false;
+  int force_generic = 0;
+  double beta1 = 0., beta2 = 0.999;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
 };
@@ -98,54 +103,54 @@ static int dalloc(ddrl_pop *h, T **p, size_t n, bool zero = true) {
 
 static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout, int hidden_act, int out_act) {
   memset(&nd, 0, sizeof(nd));
-  nd.L = nh + 1;
-  nd.d[0] = d0;
-  for (int i = 0; i < nh; ++i) nd.d[i + 1] = hidden[i];
-  nd.d[nh + 1] = dout;
+  nd.L_ = nh + 1;
+  nd.d_[0] = d0;
+  for (int i = 0; i < nh; ++i) nd.d_[i + 1] = hidden[i];
+  nd.d_[nh + 1] = dout;
   int off = 0, np = 0;
-  for (int l = 0; l < nd.L; ++l) {
-    nd.kp[l] = ddrl_roundup(nd.d[l], 4);
-    nd.offw[l] = off; off += nd.d[l + 1] * nd.kp[l];
-    nd.offb[l] = off; off += ddrl_roundup(nd.d[l + 1], 4);
-    np += nd.d[l + 1] * nd.d[l] + nd.d[l + 1];
+  for (int l = 0; l < nd.L_; ++l) {
+    nd.kp_[l] = ddrl_roundup(nd.d_[l], 4);
+    nd.offw_[l] = off; off += nd.d_[l + 1] * nd.kp_[l];
+    nd.offb_[l] = off; off += ddrl_roundup(nd.d_[l + 1], 4);
+    np += nd.d_[l + 1] * nd.d_[l] + nd.d_[l + 1];
   }
-  for (int i = 0; i <= nd.L; ++i) nd.ld[i] = ddrl_ldpad(nd.d[i]);
-  nd.stride = ddrl_roundup(off, 64);
+  for (int i = 0; i <= nd.L_; ++i) nd.ld_[i] = ddrl_ldpad(nd.d_[i]);
+  nd.stride_ = ddrl_roundup(off, 64);
   nd.np = np;
-  nd.hidden_act = hidden_act;
-  nd.out_act = out_act;
+  nd.hidden_act_ = hidden_act;
+  nd.out_act_ = out_act;
 }
 
 // flat reference order <-> padded device image of ONE agent
 static void pack_flat(const NetDesc &nd, const double *flat, float *img) {
   size_t k = 0;
-  for (int l = 0; l < nd.L; ++l) {
-    for (int n = 0; n < nd.d[l + 1]; ++n)
-      for (int c = 0; c < nd.d[l]; ++c) img[nd.offw[l] + n * nd.kp[l] + c] = (float)flat[k++];
-    for (int n = 0; n < nd.d[l + 1]; ++n) img[nd.offb[l] + n] = (float)flat[k++];
+  for (int l = 0; l < nd.L(); ++l) {
+    for (int n = 0; n < nd.d(l + 1); ++n)
+      for (int c = 0; c < nd.d(l); ++c) img[nd.offw(l) + n * nd.kp(l) + c] = (float)flat[k++];
+    for (int n = 0; n < nd.d(l + 1); ++n) img[nd.offb(l) + n] = (float)flat[k++];
   }
 }
 static void unpack_flat(const NetDesc &nd, const float *img, double *flat) {
   size_t k = 0;
-  for (int l = 0; l < nd.L; ++l) {
-    for (int n = 0; n < nd.d[l + 1]; ++n)
-      for (int c = 0; c < nd.d[l]; ++c) flat[k++] = (double)img[nd.offw[l] + n * nd.kp[l] + c];
-    for (int n = 0; n < nd.d[l + 1]; ++n) flat[k++] = (double)img[nd.offb[l] + n];
+  for (int l = 0; l < nd.L(); ++l) {
+    for (int n = 0; n < nd.d(l + 1); ++n)
+      for (int c = 0; c < nd.d(l); ++c) flat[k++] = (double)img[nd.offw(l) + n * nd.kp(l) + c];
+    for (int n = 0; n < nd.d(l + 1); ++n) flat[k++] = (double)img[nd.offb(l) + n];
   }
 }
 
 static int upload_flat(ddrl_pop *h, const NetDesc &nd, float *dst, const double *flat) {
-  std::vector<float> img((size_t)h->G * nd.stride, 0.f);
-  for (int g = 0; g < h->G; ++g) pack_flat(nd, flat + (size_t)g * nd.np, img.data() + (size_t)g * nd.stride);
+  std::vector<float> img((size_t)h->G * nd.stride(), 0.f);
+  for (int g = 0; g < h->G; ++g) pack_flat(nd, flat + (size_t)g * nd.np, img.data() + (size_t)g * nd.stride());
   HIPCHK(hipMemcpyAsync(dst, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return DDRL_OK;
 }
 static int download_flat(ddrl_pop *h, const NetDesc &nd, const float *src, double *flat) {
-  std::vector<float> img((size_t)h->G * nd.stride);
+  std::vector<float> img((size_t)h->G * nd.stride());
   HIPCHK(hipMemcpyAsync(img.data(), src, img.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (int g = 0; g < h->G; ++g) unpack_flat(nd, img.data() + (size_t)g * nd.stride, flat + (size_t)g * nd.np);
+  for (int g = 0; g < h->G; ++g) unpack_flat(nd, img.data() + (size_t)g * nd.stride(), flat + (size_t)g * nd.np);
   return DDRL_OK;
 }
 
@@ -269,7 +274,7 @@ static int validate(const ddrl_ddpg_config *c) {
 }
 
 static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc) {
-  const size_t n = (size_t)h->G * t.nd.stride;
+  const size_t n = (size_t)h->G * t.nd.stride();
   int rc;
   if ((rc = dalloc(h, &t.st.w, n))) return rc;
   if ((rc = dalloc(h, &t.st.m, n))) return rc;
@@ -277,6 +282,7 @@ static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc) {
   if ((rc = dalloc(h, &t.st.wt, n))) return rc;
   if ((rc = dalloc(h, &t.st.iter, h->G))) return rc;
   if ((rc = dalloc(h, &t.d_lr, h->G))) return rc;
+  if ((rc = dalloc(h, &t.st.lr_t, h->G))) return rc;
   if ((rc = dalloc(h, &t.d_decay, h->G))) return rc;
   t.st.lr = t.d_lr;
   t.st.decay = t.d_decay;
@@ -333,6 +339,7 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   if ((rc = dalloc(h, &h->d_loss, G))) return bail(rc);
   if ((rc = dalloc(h, &h->d_qt, (size_t)G * B))) return bail(rc);
   if ((rc = dalloc(h, &h->d_dact, (size_t)G * B * A))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_stamps, (size_t)G * 16))) return bail(rc);
   if ((rc = dalloc(h, &h->d_s, (size_t)G * S))) return bail(rc);
   if ((rc = dalloc(h, &h->d_s2, (size_t)G * S))) return bail(rc);
   if ((rc = dalloc(h, &h->d_a, (size_t)G * A))) return bail(rc);
@@ -382,9 +389,13 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   P.G = G; P.S = S; P.A = A; P.B = B; P.cap = cfg->replay_memory; P.rowlen = h->rowlen;
   P.inverting = cfg->inverting_grad ? 1 : 0;
   P.ldxc = ddrl_ldpad(S + A); P.ldxa = ddrl_ldpad(S);
+  P.ldh = 4;
+  for (int k = 0; k < 2; ++k)
+    for (int l = 1; l < h->net[k].nd.L(); ++l) P.ldh = std::max(P.ldh, h->net[k].nd.ld(l));
   double b1, b2;   // MLP.hpp:160-173
   switch (cfg->momentum) { case 0: b1 = 0.; b2 = 0.999; break; case 1: b1 = 0.9; b2 = 0.999; break;
                            case 2: b1 = 0.; b2 = 0.; break; default: b1 = 0.9; b2 = 0.; }
+  h->beta1 = b1; h->beta2 = b2;
   P.beta1 = (float)b1; P.beta2 = (float)b2; P.omb1 = (float)(1. - b1); P.omb2 = (float)(1. - b2);
   P.eps = 1e-8f;   // caffe SolverParameter.delta default
   P.fisher_beta = (float)cfg->ewc_fisher_beta;
@@ -582,9 +593,10 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
           return ddrl_fail(DDRL_EINVAL, "idx[%d][%d]=%d outside the replay of %d samples", g, i, idx[(size_t)g * B + i], h->h_len[g]);
     }
     HIPCHK(hipMemcpyAsync(h->d_idx, idx, (size_t)G * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  } else {
-    HIPCHK(replay_draw_launch(h->d_mt, h->d_mtpos, h->d_len, G, B, dmask, h->d_idx, h->stream));
   }
+  HIPCHK(replay_draw_launch(h->d_mt, h->d_mtpos, h->d_len, G, B, dmask, h->d_idx, idx ? 0 : 1, h->beta1, h->beta2,
+                            h->net[0].d_lr, h->net[1].d_lr, h->net[0].st.iter, h->net[1].st.iter,
+                            h->net[0].st.lr_t, h->net[1].st.lr_t, h->stream));
   h->P.mask = dmask;
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
@@ -599,7 +611,7 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
     h->ev_used++;
     HIPCHK(hipEventRecord(e0, h->stream));
   }
-  HIPCHK(ddpg_update_launch(&h->P, h->stream));
+  HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
   if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
@@ -643,7 +655,7 @@ extern "C" int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score, co
     }
     if (!any) continue;
     if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
-    HIPCHK(snapshot_launch(t.st.best, t.st.w, t.nd.stride, h->d_flag, h->G, h->stream));
+    HIPCHK(snapshot_launch(t.st.best, t.st.w, t.nd.stride(), h->d_flag, h->G, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   return DDRL_OK;
@@ -668,7 +680,7 @@ extern "C" int ddrl_pop_ewc_setup(ddrl_pop_t *h, const uint8_t *mask) {
     }
     if (!any) continue;
     if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
-    HIPCHK(ewc_setup_launch(t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride,
+    HIPCHK(ewc_setup_launch(t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride(),
                             h->d_flag, h->G, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if ((rc = refresh_ewc_coef(h, t))) return rc;
@@ -697,7 +709,7 @@ extern "C" int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost) {
   TrainNet &t = *train_net(h, net);
   std::fill(cost, cost + h->G, 0.0);
   if (!t.ewc.enabled) return DDRL_OK;
-  HIPCHK(ewc_cost_launch(t.st.w, t.st.wstar, t.st.fhat, t.nd.stride, h->d_cost, h->G, h->stream));
+  HIPCHK(ewc_cost_launch(t.st.w, t.st.wstar, t.st.fhat, t.nd.stride(), h->d_cost, h->G, h->stream));
   std::vector<float> c(h->G);
   HIPCHK(hipMemcpyAsync(c.data(), h->d_cost, h->G * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -751,4 +763,25 @@ extern "C" int ddrl_pop_profile_read(ddrl_pop_t *h, double *kernel_ms, int *laun
   *launches = (int)h->ev_used;
   h->ev_used = 0;
   return DDRL_OK;
+}
+
+// diagnostic: s_memtime stamps of the next/last update's phases, [G x 16] (enable, run an update, read)
+extern "C" int ddrl_pop_debug_stamps(ddrl_pop_t *h, int enable, long long *out) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  h->P.stamps = enable ? h->d_stamps : nullptr;
+  if (out) {
+    HIPCHK(hipMemcpyAsync(out, h->d_stamps, (size_t)h->G * 16 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return DDRL_OK;
+}
+
+// options: "force_generic" (0/1): run the run-time-shape kernel even when a compile-time
+// instantiation matches (parity tests exercise both on the same inputs)
+extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
+  if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  if (std::string(key) == "force_generic") { h->force_generic = value != 0; return DDRL_OK; }
+  return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);
 }

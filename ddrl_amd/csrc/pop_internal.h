@@ -5,25 +5,74 @@
 
 #define DDRL_MAXL 4          // InnerProduct layers per net = hidden (<=3) + output
 #define DDRL_MB 64           // rows per workgroup batch tile (4 MFMA m-tiles of 16)
-#define DDRL_NWAVES 4        // 256-thread workgroups: one wave per SIMD of the CU
+#ifndef DDRL_NWAVES
+#define DDRL_NWAVES 8        // 512-thread workgroups: two waves per SIMD; 2 workgroups per CU => 4 waves per SIMD
+#endif
 #define DDRL_NTHREADS (DDRL_NWAVES * 64)
 #define DDRL_MAXW 128        // max layer width handled by the fused (LDS-resident) kernels
+#define DDRL_MAXKC (DDRL_MAXW / 16)   // 16-deep k-chunks in the widest supported layer
+#define DDRL_MAXKT ((DDRL_MAXKC + DDRL_NWAVES - 1) / DDRL_NWAVES)   // dX column tiles per wave
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__host__ __device__ constexpr int ddrl_roundup(int x, int m) { return (x + m - 1) / m * m; }
+// LDS row stride for a width-n activation: multiple of 4 floats (16-B aligned float4 rows) and
+// == 4 (mod 8), so that rows 4 apart land 16 banks apart for the column-walking ds_read_b32 of the
+// dW products.
+__host__ __device__ constexpr int ddrl_ldpad(int n) {
+  int r = ddrl_roundup(n, 4);
+  while ((r & 7) != 4) r += 4;
+  return r;
+}
+
 // One MLP's shape and its padded device layout.  Per agent the net is one block of `stride`
-// floats: layer l weights at offw[l], row-major [d[l+1] x kp[l]] with kp = roundup(d[l], 4) so that
-// every row starts 16-byte aligned (pad columns hold 0 and are never updated), bias at offb[l].
+// floats: layer l weights at offw(l), row-major [d(l+1) x kp(l)] with kp = roundup(d(l), 4) so that
+// every row starts 16-byte aligned (pad columns hold 0 and stay 0), bias at offb(l).
+// Two providers with the same accessors: NetDesc (run-time shapes, the generic kernels) and
+// SNet<...> (compile-time shapes: every loop bound, guard and offset folds to a constant).
 struct NetDesc {
-  int L;
-  int d[DDRL_MAXL + 1];
-  int kp[DDRL_MAXL];
-  int ld[DDRL_MAXL + 1];    // LDS row stride of the activation of width d[i] (see ldpad())
-  int offw[DDRL_MAXL];
-  int offb[DDRL_MAXL];
-  int stride;               // floats per agent (multiple of 64 => 256-B aligned blocks)
-  int np;                   // logical (flat, reference-order) parameter count
-  int hidden_act, out_act;
+  int L_;
+  int d_[DDRL_MAXL + 1];
+  int kp_[DDRL_MAXL];
+  int ld_[DDRL_MAXL + 1];    // LDS row stride of the activation of width d(i) (ddrl_ldpad)
+  int offw_[DDRL_MAXL];
+  int offb_[DDRL_MAXL];
+  int stride_;               // floats per agent (multiple of 64 => 256-B aligned blocks)
+  int np;                    // logical (flat, reference-order) parameter count
+  int hidden_act_, out_act_;
+  __host__ __device__ int L() const { return L_; }
+  __host__ __device__ int d(int i) const { return d_[i]; }
+  __host__ __device__ int kp(int l) const { return kp_[l]; }
+  __host__ __device__ int ld(int i) const { return ld_[i]; }
+  __host__ __device__ int offw(int l) const { return offw_[l]; }
+  __host__ __device__ int offb(int l) const { return offb_[l]; }
+  __host__ __device__ int stride() const { return stride_; }
+  __host__ __device__ int hidden_act() const { return hidden_act_; }
+  __host__ __device__ int out_act() const { return out_act_; }
+};
+
+template <int HACT, int OACT, int... D>
+struct SNet {
+  static constexpr int NL = (int)sizeof...(D) - 1;
+  __host__ __device__ static constexpr int L() { return NL; }
+  __host__ __device__ static constexpr int d(int i) { constexpr int dd[] = {D...}; return dd[i]; }
+  __host__ __device__ static constexpr int kp(int l) { return ddrl_roundup(d(l), 4); }
+  __host__ __device__ static constexpr int ld(int i) { return ddrl_ldpad(d(i)); }
+  __host__ __device__ static constexpr int offw(int l) {
+    int off = 0;
+    for (int i = 0; i < l; ++i) off += d(i + 1) * kp(i) + ddrl_roundup(d(i + 1), 4);
+    return off;
+  }
+  __host__ __device__ static constexpr int offb(int l) { return offw(l) + d(l + 1) * kp(l); }
+  __host__ __device__ static constexpr int stride() { return ddrl_roundup(offw(NL), 64); }
+  __host__ __device__ static constexpr int hidden_act() { return HACT; }
+  __host__ __device__ static constexpr int out_act() { return OACT; }
+  // does a run-time descriptor describe this shape?
+  static bool matches(const NetDesc &n) {
+    if (n.L_ != NL || n.hidden_act_ != HACT || n.out_act_ != OACT) return false;
+    for (int i = 0; i <= NL; ++i) if (n.d_[i] != d(i)) return false;
+    return n.stride_ == stride();
+  }
 };
 
 // Per-net optimiser / EWC state pointers (device), each [G x stride] unless noted
@@ -37,6 +86,7 @@ struct NetState {
   float *fisher_nbr;        // [G]
   float *ewc_coef;          // [G] ewc * decay_multiplier if penalty live else 0
   const float *lr;          // [G]
+  float *lr_t;              // [G] lr * sqrt(1-beta2^t)/(1-beta1^t) for the coming update (prep kernel)
   const float *decay;       // [G] L2 weight decay (<0 or 0: off), null if never used
 };
 
@@ -46,7 +96,7 @@ struct DdpgParams {
   int G, S, A, B, cap, rowlen;
   int inverting;
   int ldxc, ldxa;           // LDS strides of the critic / actor input tiles
-  int ldh;                  // LDS row stride reserved for the two hidden-activation buffers
+  int ldh;                  // LDS row stride reserved for each hidden-activation buffer
   float beta1, beta2, omb1, omb2, eps;
   float fisher_beta;
   const float *rep;         // [G x cap x rowlen]  rows: s, a, s2, r, goal
@@ -57,14 +107,5 @@ struct DdpgParams {
   float *loss_out;          // [G]
   float *qt_out;            // [G x B] or null
   float *dact_out;          // [G x B x A] or null
+  long long *stamps;        // [G x 16] s_memtime at phase boundaries (diagnostic), or null
 };
-
-__host__ __device__ inline int ddrl_roundup(int x, int m) { return (x + m - 1) / m * m; }
-// LDS row stride for a width-n activation: multiple of 4 floats (16-B aligned float4 rows) and
-// == 4 (mod 8), so that rows 4 apart land 16 banks apart for the column-walking ds_read_b32 of the
-// dW products.
-__host__ __device__ inline int ddrl_ldpad(int n) {
-  int r = ddrl_roundup(n, 4);
-  while ((r & 7) != 4) r += 4;
-  return r;
-}

@@ -4,7 +4,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libddrl_pop.so")
+SO = os.environ.get("DDRL_POP_SO") or os.path.join(HERE, "libddrl_pop.so")   # DDRL_POP_SO: dev experiments only
 DDRL_MAX_HIDDEN = 3
 
 
@@ -66,6 +66,8 @@ SYMBOLS = [
     ("ddrl_pop_get_ewc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     ("ddrl_pop_set_profiling", _i, [_vp, _i]),
     ("ddrl_pop_profile_read", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
+    ("ddrl_pop_debug_stamps", _i, [_vp, _i, _vp]),
+    ("ddrl_pop_set_option", _i, [_vp, _cp, _i]),
 ]
 
 _lib = None

@@ -180,3 +180,6 @@ class DdpgPopulation:
         ms, n = C.c_double(), C.c_int()
         _l.check(self.L.ddrl_pop_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_option(self, key, value):
+        _l.check(self.L.ddrl_pop_set_option(self.h, key.encode(), int(value)))

@@ -143,6 +143,12 @@ int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat,
  * returns the summed kernel time and the number of launches since the last read. */
 int ddrl_pop_set_profiling(ddrl_pop_t *h, int on);
 int ddrl_pop_profile_read(ddrl_pop_t *h, double *kernel_ms, int *launches);
+/* diagnostic: enable != 0 makes the following updates record s_memtime at their phase boundaries;
+ * out (may be NULL) receives the stamps of the last update, [G x 16] */
+int ddrl_pop_debug_stamps(ddrl_pop_t *h, int enable, long long *out);
+/* "force_generic" = 1: use the run-time-shape kernel even where a compile-time instantiation of the
+ * update kernel matches the configured nets (both are held to the same parity tests) */
+int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value);
 
 #ifdef __cplusplus
 }

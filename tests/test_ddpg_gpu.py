@@ -36,15 +36,19 @@ def test_replay_indices_bit_exact(ora):
             assert np.array_equal(got[g], want), (it, g)
 
 
-@pytest.mark.parametrize("hidden_a,hidden_q,wscale,sweep", [
-    ((100, 100), (100, 100), 0.01, False),      # BASELINE.md section 3 "mid", reference init scale
-    ((100, 100), (100, 100), 0.1, True),        # hyper-parameter sweep
-    ((20,), (50, 7), 0.1, True),                # "small": agent/deepqn/data/ddpg-cp.ini:15-16
-    ((128, 96, 33), (17, 128, 5), 0.1, True),   # ragged widths, 3 hidden layers
+# generic=False: the compile-time-shape instantiation is used where one matches ("mid", "small");
+# generic=True forces the run-time-shape kernel on the same inputs.
+@pytest.mark.parametrize("hidden_a,hidden_q,wscale,sweep,generic", [
+    ((100, 100), (100, 100), 0.01, False, False),      # BASELINE.md section 3 "mid", reference init scale
+    ((100, 100), (100, 100), 0.1, True, False),        # hyper-parameter sweep
+    ((100, 100), (100, 100), 0.1, True, True),
+    ((20,), (50, 7), 0.1, True, False),                # "small": agent/deepqn/data/ddpg-cp.ini:15-16
+    ((20,), (50, 7), 0.1, True, True),
+    ((128, 96, 33), (17, 128, 5), 0.1, True, False),   # ragged widths, 3 hidden layers (generic kernel)
 ])
-def test_one_update_matches_oracle(ora, hidden_a, hidden_q, wscale, sweep):
+def test_one_update_matches_oracle(ora, hidden_a, hidden_q, wscale, sweep, generic):
     G = 4
-    pop, agents = make_pair(ora, G=G, hidden_a=hidden_a, hidden_q=hidden_q, wscale=wscale, sweep=sweep)
+    pop, agents = make_pair(ora, G=G, hidden_a=hidden_a, hidden_q=hidden_q, wscale=wscale, sweep=sweep, force_generic=generic)
     ws_prev = [pop.weights(n) for n in range(4)]
     rng = np.random.RandomState(5)
     idx = rng.randint(0, 1000, (G, 64)).astype(np.int32)
@@ -171,11 +175,13 @@ def test_default_init_is_gaussian_001():
     assert np.array_equal(pop.weights(1), pop.weights(3)) and np.array_equal(pop.weights(0), pop.weights(2))
 
 
-def test_ewc_lifecycle_matches_oracle(ora):
+@pytest.mark.parametrize("hidden,for_critic", [((32, 32), 1), ((100, 100), 1), ((100, 100), 0)])
+def test_ewc_lifecycle_matches_oracle(ora, hidden, for_critic):
     import oracle.oracle as o
-    kw = dict(G=3, hidden_a=(32, 32), hidden_q=(32, 32), ewc=100.0, ewc_decay=0.9, ewc_fisher_beta=0.999,
-              ewc_for_critic=1, ewc_best_method=0, wscale=0.1, seed=3)
+    kw = dict(G=3, hidden_a=hidden, hidden_q=hidden, ewc=100.0, ewc_decay=0.9, ewc_fisher_beta=0.999,
+              ewc_for_critic=for_critic, ewc_best_method=0, wscale=0.1, seed=3)
     pop, agents = make_pair(ora, **kw)
+    ewc_nets = (0, 1) if for_critic else (0,)
     for it in range(4):                       # task 1: accumulate Fisher
         pop.update()
         for ag in agents:
@@ -191,7 +197,7 @@ def test_ewc_lifecycle_matches_oracle(ora):
     pop.ewc_setup()                           # development switch
     for ag in agents:
         ag.ewc_setup()
-    for net in (0, 1):
+    for net in ewc_nets:
         st = pop.ewc_state(net)
         for g, ag in enumerate(agents):
             so = ag.nets[net].ewc_state()
@@ -202,7 +208,7 @@ def test_ewc_lifecycle_matches_oracle(ora):
     # ewc_setup loads w* back into the live net (DODevMLP.hpp:616)
     assert np.array_equal(pop.weights(0), pop.ewc_state(0)["wstar"])
     # from here on hold each update to the bar from synchronised state, penalty live
-    for ag_net in (0, 1):
+    for ag_net in ewc_nets:
         st = pop.ewc_state(ag_net)
         for g, ag in enumerate(agents):
             n = ag.nets[ag_net]
@@ -219,7 +225,7 @@ def test_ewc_lifecycle_matches_oracle(ora):
         pop.ewc_decay_update()
         for ag in agents:
             o.lib().ora_mlp_ewc_decay_update(ag.ann.h); o.lib().ora_mlp_ewc_decay_update(ag.qnn.h)
-    for net in (0, 1):
+    for net in ewc_nets:
         sync_oracle_from_gpu(pop, agents)
         cost = pop.ewc_cost(net)
         st = pop.ewc_state(net)
