@@ -1,0 +1,767 @@
+// cmaes.hip -- CMA-ES policy search on gfx950 behind the ddrl_cmaes_* C ABI.
+//
+// What it replaces: the vendored c-cmaes, /root/reference/agent/cmaes/src/cmaes.c, as driven by
+// CMAESAg (/root/reference/agent/cmaes/include/CMAESAg.hpp:50-253).
+//
+// Device (fp32 matrices, fp64 vectors/scalars):
+//   cmaes_gemm_nt       X = m + sigma * DZ * B^T            (cmaes.c:645-652)        fp32 MFMA GEMM
+//   cmaes_rank_kernel   Sorted_index                        (cmaes.c:2989-3000)      exact LDS sort
+//   cmaes_vec_kernel    mean, BDz, ps, hsig, pc, sigma      (cmaes.c:826-898, 952)   one workgroup
+//   cmaes_pack_y        y_k = sqrt(w_k) (x_{k:lambda} - m_old) / sigma  (cmaes.c:985-989)
+//   cmaes_gemm_nt       C <- a C + c1 pc pc^T + cmu Y Y^T   (cmaes.c:979-991)        fp32 MFMA GEMM
+// Host (fp64): parameter defaults, the reference's LCG + Box-Muller stream (sequential by
+// construction: a shuffle table indexed by the previous output), the lazily scheduled eigen-
+// decomposition (Householder + QL, the JAMA routines c-cmaes uses).
+#include "../../include/ddrl_pop.h"
+#include "pop_internal.h"
+#include "host_util.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return ddrl_fail(DDRL_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// device scalar block (doubles)
+enum { SC_SIGMA = 0, SC_SIGMA_C, SC_PSXPS, SC_HSIG, SC_FBEST, SC_N };
+
+__device__ __forceinline__ f32x4 cm_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C[M x N] (+epilogue) = A[M x K] * Bt[N x K]^T, all row-major with row strides lda/ldb/ldc (floats,
+// multiples of 4); K a multiple of 16 (operands are zero-padded by their producers).
+// 64 x 64 tile per 256-thread workgroup, 16-deep k-steps staged through LDS, each wave a 32 x 32
+// quadrant = 2 x 2 MFMA tiles of v_mfma_f32_16x16x4_f32.
+// MODE 0 (sampling):    C[r][c] = mean[c] + sigma * acc
+// MODE 1 (covariance):  C[r][c] = cc * C[r][c] + c1 * pc[r] * pc[c] + cmu * acc, with
+//                       cc = (1 - c1 - cmu) + c1 * (1 - hsig) * ccumcov * (2 - ccumcov)   (cmaes.c:981-984)
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256)
+cmaes_gemm_nt(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb,
+              float *__restrict__ C, int ldc, int M, int N, int K,
+              const double *__restrict__ vec, const double *__restrict__ sc,
+              double c1, double cmu, double ccumcov, int only_row) {
+  __shared__ __align__(16) float As[64][20];   // 16 + 4 pad: rows stay 16-B aligned
+  __shared__ __align__(16) float Bs[64][20];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int bm = blockIdx.y * 64, bn = blockIdx.x * 64;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int lr = tid >> 2, lk = (tid & 3) * 4;          // staging: one float4 of A and of Bt per thread
+  const int ar = min(bm + lr, M - 1), br = min(bn + lr, N - 1);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const f32x4 av = *(const f32x4 *)(A + (size_t)ar * lda + k0 + lk);
+    const f32x4 bv = *(const f32x4 *)(Bt + (size_t)br * ldb + k0 + lk);
+    __syncthreads();
+    *(f32x4 *)&As[lr][lk] = av;
+    *(f32x4 *)&Bs[lr][lk] = bv;
+    __syncthreads();
+    f32x4 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *(const f32x4 *)&As[wr * 32 + i * 16 + c][4 * g];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const f32x4 *)&Bs[wc * 32 + j * 16 + c][4 * g];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = cm_mfma(a[i][e], b[j][e], acc[i][j]);
+  }
+  double cc = 0.;
+  float sigma = 0.f;
+  if (MODE == 0) sigma = (float)sc[SC_SIGMA];
+  else cc = (1. - c1 - cmu) + c1 * (1. - sc[SC_HSIG]) * ccumcov * (2. - ccumcov);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bm + wr * 32 + i * 16 + 4 * g + r, col = bn + wc * 32 + j * 16 + c;
+        if (row < M && col < N) {
+          if (MODE == 0) {
+            const int orow = only_row >= 0 ? only_row : row;
+            C[(size_t)orow * ldc + col] = (float)vec[col] + sigma * acc[i][j][r];
+          } else {
+            float *p = C + (size_t)row * ldc + col;
+            *p = (float)(cc * (double)*p + c1 * vec[row] * vec[col] + cmu * (double)acc[i][j][r]);
+          }
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sorted_index (cmaes.c:2989-3000): ascending insertion sort with a strict '<' break, i.e. among
+// equal values the LATER index comes first.  Equivalent total order: (value ascending, index
+// descending); sorted here with a bitonic network over (fp64 key, index) pairs in LDS (one workgroup).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool rank_after(unsigned long long ka, unsigned int ia, unsigned long long kb, unsigned int ib) {
+  return ka > kb || (ka == kb && ia < ib);         // equal values: the later index sorts first
+}
+
+__global__ void __launch_bounds__(1024)
+cmaes_rank_kernel(const double *__restrict__ f, int n, int npow2, int *__restrict__ index) {
+  extern __shared__ unsigned long long keys[];     // [npow2] keys, then [npow2] u32 indices
+  unsigned int *ids = (unsigned int *)(keys + npow2);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < npow2; i += 1024) {
+    unsigned long long k = ~0ull;
+    if (i < n) {
+      double v = f[i];
+      if (v == 0.) v = 0.;                         // -0 == +0 for the reference's '<'
+      unsigned long long u = (unsigned long long)__double_as_longlong(v);
+      k = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    }
+    keys[i] = k;
+    ids[i] = i < n ? (unsigned int)i : 0u;         // pads: max key, smallest index => sort last
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < npow2 / 2; t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        const unsigned int ia = ids[lo], ib = ids[hi];
+        if (rank_after(a, ia, b, ib) == up && !(a == b && ia == ib)) {
+          keys[lo] = b; keys[hi] = a; ids[lo] = ib; ids[hi] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += 1024) index[i] = (int)ids[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The O(N mu + N^2) vector part of cmaes_UpdateDistribution (cmaes.c:825-898, 952), one workgroup.
+// ---------------------------------------------------------------------------------------------
+struct CmaesVecArgs {
+  int N, ldx, ldn, lambda, mu;
+  double mueff, cs, damps, ccumcov, chiN, gen;
+  const float *X, *B;
+  const double *fit;
+  const int *index;
+  const double *weights;
+  double *xmean, *xold, *ps, *pc, *BDz, *tmp, *D, *sc, *xbest;
+};
+
+__global__ void __launch_bounds__(1024)
+cmaes_vec_kernel(const CmaesVecArgs a) {
+  __shared__ double red[1024];
+  const int tid = threadIdx.x, N = a.N;
+  // flat fitness: sigma *= exp(0.2 + cs/damps)   (cmaes.c:826-831)
+  if (tid == 0) {
+    double sigma = a.sc[SC_SIGMA];
+    if (a.fit[a.index[0]] == a.fit[a.index[a.lambda / 2]]) sigma *= exp(0.2 + a.cs / a.damps);
+    a.sc[SC_SIGMA] = sigma;
+    a.sc[SC_SIGMA_C] = sigma;                      // Adapt_C2 uses sigma before its final update
+  }
+  // best-ever solution (cmaes.c:834-841)
+  const int ibest = a.index[0];
+  const bool newbest = a.sc[SC_FBEST] > a.fit[ibest] || a.gen == 1.;
+  __syncthreads();
+  if (newbest) {
+    for (int i = tid; i < N; i += 1024) a.xbest[i] = (double)a.X[(size_t)ibest * a.ldx + i];
+    if (tid == 0) a.sc[SC_FBEST] = a.fit[ibest];
+  }
+  const double sigma = a.sc[SC_SIGMA];
+  // xmean = sum_k w_k x_{k:lambda};  BDz = sqrt(mueff) (xmean - xold) / sigma   (cmaes.c:846-852)
+  for (int i = tid; i < N; i += 1024) {
+    const double old = a.xmean[i];
+    double m = 0.;
+    for (int k = 0; k < a.mu; ++k) m += a.weights[k] * (double)a.X[(size_t)a.index[k] * a.ldx + i];
+    a.xold[i] = old;
+    a.xmean[i] = m;
+    a.BDz[i] = sqrt(a.mueff) * (m - old) / sigma;
+  }
+  __syncthreads();
+  // z = D^-1 B^T BDz   (cmaes.c:855-862)
+  for (int i = tid; i < N; i += 1024) {
+    double s = 0.;
+    for (int j = 0; j < N; ++j) s += (double)a.B[(size_t)j * a.ldn + i] * a.BDz[j];
+    a.tmp[i] = s / a.D[i];
+  }
+  __syncthreads();
+  // ps = (1 - cs) ps + sqrt(cs (2 - cs)) B z   (cmaes.c:878-886)
+  double part = 0.;
+  for (int i = tid; i < N; i += 1024) {
+    double s = 0.;
+    for (int j = 0; j < N; ++j) s += (double)a.B[(size_t)i * a.ldn + j] * a.tmp[j];
+    const double p = (1. - a.cs) * a.ps[i] + sqrt(a.cs * (2. - a.cs)) * s;
+    a.ps[i] = p;
+    part += p * p;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  const double psxps = red[0];
+  // hsig, pc   (cmaes.c:893-898)
+  const double hsig = (sqrt(psxps) / sqrt(1. - pow(1. - a.cs, 2. * a.gen)) / a.chiN < 1.4 + 2. / (N + 1)) ? 1. : 0.;
+  for (int i = tid; i < N; i += 1024)
+    a.pc[i] = (1. - a.ccumcov) * a.pc[i] + hsig * sqrt(a.ccumcov * (2. - a.ccumcov)) * a.BDz[i];
+  if (tid == 0) {
+    a.sc[SC_PSXPS] = psxps;
+    a.sc[SC_HSIG] = hsig;
+    a.sc[SC_SIGMA] = sigma * exp(((sqrt(psxps) / a.chiN) - 1.) * a.cs / a.damps);   // cmaes.c:952
+  }
+}
+
+// Y[i][k] = sqrt(w_k) (x_{k:lambda,i} - xold_i) / sigma  (N x mu16, zero padded): the rank-mu term
+// sum_k w_k y_k y_k^T / sigma^2 (cmaes.c:985-989) becomes Y Y^T, one k-contiguous operand used on both
+// sides of the product, which keeps C exactly symmetric in fp32
+__global__ void cmaes_pack_y(const float *__restrict__ X, int ldx, const int *__restrict__ index,
+                             const double *__restrict__ weights, const double *__restrict__ xold,
+                             const double *__restrict__ sc, int N, int mu, int mu16, float *__restrict__ Y) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (k >= mu16 || i >= N) return;
+  float y = 0.f;
+  if (k < mu) y = (float)(sqrt(weights[k]) * ((double)X[(size_t)index[k] * ldx + i] - xold[i]) / sc[SC_SIGMA_C]);
+  Y[(size_t)i * mu16 + k] = y;
+}
+
+// any |x_i| >= bound per individual (CMAESAg::is_feasible, CMAESAg.hpp:135-142)
+__global__ void cmaes_infeasible_kernel(const float *__restrict__ X, int ldx, int N, float bound, int *__restrict__ flag) {
+  const int k = blockIdx.x;
+  int bad = 0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) bad |= fabsf(X[(size_t)k * ldx + i]) >= bound;
+  bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) flag[k] = bad;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct ddrl_cmaes {
+  int N = 0, lambda = 0, mu = 0, device = 0;
+  int ldn = 0, mu16 = 0;                 // padded row strides (multiples of 16)
+  double mueff, mucov, cs, ccumcov, ccov, damps, modulo, chiN;
+  std::vector<double> weights;
+  // reference random stream (cmaes.c:2421-2482)
+  long aktseed = 0, aktrand = 0, rgrand[32];
+  int flgstored = 0;
+  double hold = 0;
+  // schedule
+  double gen = 0, countevals = 0, genOfEigensysUpdate = 0;
+  int state = 0, eigen_uptodate = 1;
+  std::vector<double> D, B;              // host copies (fp64): D [N], B [N x N]
+  hipStream_t stream = nullptr;
+  // device
+  float *d_X = nullptr, *d_DZ = nullptr, *d_B = nullptr, *d_C = nullptr, *d_Y = nullptr;
+  double *d_fit = nullptr;
+  double *d_xmean = nullptr, *d_xold = nullptr, *d_ps = nullptr, *d_pc = nullptr, *d_BDz = nullptr, *d_tmp = nullptr,
+         *d_D = nullptr, *d_w = nullptr, *d_sc = nullptr, *d_xbest = nullptr;
+  int *d_index = nullptr, *d_flag = nullptr;
+  std::vector<void *> allocs;
+};
+
+template <class T>
+static int cm_alloc(ddrl_cmaes *h, T **p, size_t n) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) return ddrl_fail(DDRL_ENOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+  h->allocs.push_back(q);
+  e = hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream);
+  if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "hipMemset: %s", hipGetErrorString(e));
+  *p = (T *)q;
+  return DDRL_OK;
+}
+
+// cmaes_random_Start / _Uniform / _Gauss (cmaes.c:2421-2482)
+static void rnd_start(ddrl_cmaes *t, unsigned long inseed) {
+  t->flgstored = 0;
+  while (inseed > 2e9) inseed /= 2;
+  if (inseed < 1) inseed = 1;
+  t->aktseed = (long)inseed;
+  for (int i = 39; i >= 0; --i) {
+    long tmp = t->aktseed / 127773;
+    t->aktseed = 16807 * (t->aktseed - tmp * 127773) - 2836 * tmp;
+    if (t->aktseed < 0) t->aktseed += 2147483647;
+    if (i < 32) t->rgrand[i] = t->aktseed;
+  }
+  t->aktrand = t->rgrand[0];
+}
+static double rnd_uniform(ddrl_cmaes *t) {
+  long tmp = t->aktseed / 127773;
+  t->aktseed = 16807 * (t->aktseed - tmp * 127773) - 2836 * tmp;
+  if (t->aktseed < 0) t->aktseed += 2147483647;
+  tmp = t->aktrand / 67108865;
+  t->aktrand = t->rgrand[tmp];
+  t->rgrand[tmp] = t->aktseed;
+  return (double)(t->aktrand) / (2.147483647e9);
+}
+static double rnd_gauss(ddrl_cmaes *t) {
+  if (t->flgstored) { t->flgstored = 0; return t->hold; }
+  double x1, x2, rquad;
+  do {
+    x1 = 2.0 * rnd_uniform(t) - 1.0;
+    x2 = 2.0 * rnd_uniform(t) - 1.0;
+    rquad = x1 * x1 + x2 * x2;
+  } while (rquad >= 1 || rquad <= 0);
+  const double fac = sqrt(-2.0 * log(rquad) / rquad);
+  t->flgstored = 1;
+  t->hold = fac * x1;
+  return fac * x2;
+}
+
+// Symmetric eigendecomposition as c-cmaes does it: Householder tridiagonalisation followed by QL
+// with implicit shifts, eigenvalues sorted ascending (cmaes.c:1951-2261; the JAMA tred2/tql2).
+namespace eig {
+static inline double hyp(double a, double b) {
+  double r = 0;
+  if (std::fabs(a) > std::fabs(b)) { r = b / a; r = std::fabs(a) * std::sqrt(1 + r * r); }
+  else if (b != 0) { r = a / b; r = std::fabs(b) * std::sqrt(1 + r * r); }
+  return r;
+}
+static void tridiag(int n, std::vector<double> &Vm, double *d, double *e) {
+  auto V = [&](int i, int j) -> double & { return Vm[(size_t)i * n + j]; };
+  for (int j = 0; j < n; ++j) d[j] = V(n - 1, j);
+  for (int i = n - 1; i > 0; --i) {
+    double scale = 0., h = 0.;
+    for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+    if (scale == 0.) {
+      e[i] = d[i - 1];
+      for (int j = 0; j < i; ++j) { d[j] = V(i - 1, j); V(i, j) = 0.; V(j, i) = 0.; }
+    } else {
+      for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+      double f = d[i - 1], g = std::sqrt(h);
+      if (f > 0) g = -g;
+      e[i] = scale * g;
+      h -= f * g;
+      d[i - 1] = f - g;
+      for (int j = 0; j < i; ++j) e[j] = 0.;
+      for (int j = 0; j < i; ++j) {
+        f = d[j];
+        V(j, i) = f;
+        g = e[j] + V(j, j) * f;
+        for (int k = j + 1; k <= i - 1; ++k) { g += V(k, j) * d[k]; e[k] += V(k, j) * f; }
+        e[j] = g;
+      }
+      f = 0.;
+      for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+      const double hh = f / (h + h);
+      for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+      for (int j = 0; j < i; ++j) {
+        f = d[j]; g = e[j];
+        for (int k = j; k <= i - 1; ++k) V(k, j) -= (f * e[k] + g * d[k]);
+        d[j] = V(i - 1, j);
+        V(i, j) = 0.;
+      }
+    }
+    d[i] = h;
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    V(n - 1, i) = V(i, i);
+    V(i, i) = 1.;
+    const double h = d[i + 1];
+    if (h != 0.) {
+      for (int k = 0; k <= i; ++k) d[k] = V(k, i + 1) / h;
+      for (int j = 0; j <= i; ++j) {
+        double g = 0.;
+        for (int k = 0; k <= i; ++k) g += V(k, i + 1) * V(k, j);
+        for (int k = 0; k <= i; ++k) V(k, j) -= g * d[k];
+      }
+    }
+    for (int k = 0; k <= i; ++k) V(k, i + 1) = 0.;
+  }
+  for (int j = 0; j < n; ++j) { d[j] = V(n - 1, j); V(n - 1, j) = 0.; }
+  V(n - 1, n - 1) = 1.;
+  e[0] = 0.;
+}
+static void ql(int n, double *d, double *e, std::vector<double> &Vm) {
+  auto V = [&](int i, int j) -> double & { return Vm[(size_t)i * n + j]; };
+  double f = 0., tst1 = 0.;
+  const double eps = 2.22e-16;
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.;
+  for (int l = 0; l < n; ++l) {
+    tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+    int m = l;
+    while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+    if (m > l) {
+      do {
+        double g = d[l];
+        double p = (d[l + 1] - g) / (2.0 * e[l]);
+        double r = hyp(p, 1.);
+        if (p < 0) r = -r;
+        d[l] = e[l] / (p + r);
+        d[l + 1] = e[l] * (p + r);
+        const double dl1 = d[l + 1];
+        double h = g - d[l];
+        for (int i = l + 2; i < n; ++i) d[i] -= h;
+        f += h;
+        p = d[m];
+        double c = 1., c2 = c, c3 = c, s = 0., s2 = 0.;
+        const double el1 = e[l + 1];
+        for (int i = m - 1; i >= l; --i) {
+          c3 = c2; c2 = c; s2 = s;
+          g = c * e[i];
+          h = c * p;
+          r = hyp(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r;
+          c = p / r;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+          for (int k = 0; k < n; ++k) {
+            h = V(k, i + 1);
+            V(k, i + 1) = s * V(k, i) + c * h;
+            V(k, i) = c * V(k, i) - s * h;
+          }
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+      } while (std::fabs(e[l]) > eps * tst1);
+    }
+    d[l] += f;
+    e[l] = 0.;
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    int k = i;
+    double p = d[i];
+    for (int j = i + 1; j < n; ++j) if (d[j] < p) { k = j; p = d[j]; }
+    if (k != i) {
+      d[k] = d[i]; d[i] = p;
+      for (int j = 0; j < n; ++j) std::swap(V(j, i), V(j, k));
+    }
+  }
+}
+}  // namespace eig
+
+static int upload_BD(ddrl_cmaes *h) {
+  const int N = h->N;
+  std::vector<float> Bf((size_t)N * h->ldn, 0.f);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) Bf[(size_t)i * h->ldn + j] = (float)h->B[(size_t)i * N + j];
+  HIPCHK(hipMemcpyAsync(h->d_B, Bf.data(), Bf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_D, h->D.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+// cmaes_UpdateEigensystem(t, 0) (cmaes.c:1885-1947) with the CPU-time gate off (maxtime = 1.0)
+static int update_eigensystem(ddrl_cmaes *h) {
+  if (h->eigen_uptodate) return DDRL_OK;
+  if (h->gen < h->genOfEigensysUpdate + h->modulo) return DDRL_OK;
+  const int N = h->N;
+  std::vector<float> Cf((size_t)N * h->ldn);
+  HIPCHK(hipMemcpyAsync(Cf.data(), h->d_C, Cf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<double> Q((size_t)N * N), e(N + 1);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j <= i; ++j) Q[(size_t)i * N + j] = Q[(size_t)j * N + i] = (double)Cf[(size_t)i * h->ldn + j];
+  eig::tridiag(N, Q, h->D.data(), e.data());
+  eig::ql(N, h->D.data(), e.data(), Q);
+  for (int i = 0; i < N; ++i) h->D[i] = std::sqrt(h->D[i]);
+  h->B = Q;
+  h->eigen_uptodate = 1;
+  h->genOfEigensysUpdate = h->gen;
+  return upload_BD(h);
+}
+
+extern "C" int ddrl_cmaes_create(int N, const double *xstart, const double *stds, long seed, int lambda, int device,
+                                 ddrl_cmaes_t **out) {
+  if (!xstart || !stds || !out || N < 1) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  if (seed < 1) return ddrl_fail(DDRL_EINVAL, "seed must be >= 1 (the reference's seed 0 = wall clock, cmaes.c:2406-2410)");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ddrl_fail(DDRL_EHIP, "no HIP device: libddrl_pop has no CPU path");
+  ddrl_cmaes *h = new ddrl_cmaes();
+  auto bail = [&](int code) { ddrl_cmaes_destroy(h); return code; };
+  if (device >= 0) h->device = device; else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+  if (hipSetDevice(h->device) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "hipSetDevice failed"));
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "hipStreamCreate failed"));
+  // parameter defaults: cmaes_readpara_init (cmaes.c:2545-2578) + SupplementDefaults (:2772-2851)
+  // + SetWeights "log" (:2857-2891)
+  h->N = N;
+  if (lambda < 2) lambda = 4 + (int)(3 * log((double)N));
+  if (lambda > 8192) return bail(ddrl_fail(DDRL_EINVAL, "lambda > 8192 not supported by the LDS ranking kernel"));
+  h->lambda = lambda;
+  h->mu = lambda / 2;
+  h->weights.resize(h->mu);
+  double s1 = 0, s2 = 0;
+  for (int i = 0; i < h->mu; ++i) h->weights[i] = log(h->mu + 1.) - log(i + 1.);
+  for (int i = 0; i < h->mu; ++i) { s1 += h->weights[i]; s2 += h->weights[i] * h->weights[i]; }
+  h->mueff = s1 * s1 / s2;
+  for (int i = 0; i < h->mu; ++i) h->weights[i] /= s1;
+  h->cs = (h->mueff + 2.) / (N + h->mueff + 3.);
+  h->ccumcov = 4. / (N + 4);
+  h->mucov = h->mueff;
+  const double t1 = 2. / ((N + 1.4142) * (N + 1.4142));
+  double t2 = (2. * h->mueff - 1.) / ((N + 2.) * (N + 2.) + h->mueff);
+  t2 = (t2 > 1) ? 1 : t2;
+  t2 = (1. / h->mucov) * t1 + (1. - 1. / h->mucov) * t2;
+  h->ccov = t2;
+  const double stopMaxFunEvals = 1 * 900 * (N + 3) * (N + 3);
+  const double stopMaxIter = ceil((double)(stopMaxFunEvals / lambda));
+  h->damps = 1 * (1 + 2 * std::max(0., sqrt((h->mueff - 1.) / (N + 1.)) - 1))
+      * std::max(0.3, 1. - (double)N / (1e-6 + std::min(stopMaxIter, stopMaxFunEvals / lambda))) + h->cs;
+  h->modulo = 1. / h->ccov / (double)(N) / 10.;
+  rnd_start(h, (unsigned long)seed);
+  // cmaes_init_final (cmaes.c:279-398)
+  double trace = 0.;
+  for (int i = 0; i < N; ++i) trace += stds[i] * stds[i];
+  const double sigma = sqrt(trace / N);
+  h->chiN = sqrt((double)N) * (1. - 1. / (4. * N) + 1. / (21. * N * N));
+  h->ldn = ddrl_roundup(N, 16);
+  h->mu16 = ddrl_roundup(h->mu, 16);
+  h->D.assign(N, 0.);
+  h->B.assign((size_t)N * N, 0.);
+  std::vector<float> Cf((size_t)N * h->ldn, 0.f);
+  for (int i = 0; i < N; ++i) {
+    h->B[(size_t)i * N + i] = 1.;
+    h->D[i] = stds[i] * sqrt(N / trace);
+    Cf[(size_t)i * h->ldn + i] = (float)(h->D[i] * h->D[i]);
+  }
+  int rc;
+  const size_t L = lambda, ldn = h->ldn;
+  if ((rc = cm_alloc(h, &h->d_X, L * ldn))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_DZ, L * ldn))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_B, (size_t)N * ldn))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_C, (size_t)N * ldn))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_Y, (size_t)N * h->mu16))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_fit, L))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_xmean, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_xold, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_ps, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_pc, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_BDz, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_tmp, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_D, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_w, h->mu))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_sc, SC_N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_xbest, N))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_index, L))) return bail(rc);
+  if ((rc = cm_alloc(h, &h->d_flag, L))) return bail(rc);
+  double sc[SC_N] = {sigma, sigma, 0., 0., 0.};
+  auto up = [&](void *dst, const void *src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, h->stream); };
+  if (up(h->d_C, Cf.data(), Cf.size() * 4) != hipSuccess || up(h->d_xmean, xstart, N * 8) != hipSuccess ||
+      up(h->d_xold, xstart, N * 8) != hipSuccess || up(h->d_w, h->weights.data(), h->mu * 8) != hipSuccess ||
+      up(h->d_sc, sc, sizeof(sc)) != hipSuccess)
+    return bail(ddrl_fail(DDRL_EHIP, "initial upload failed"));
+  if ((rc = upload_BD(h))) return bail(rc);
+  *out = h;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_destroy(ddrl_cmaes_t *h) {
+  if (!h) return DDRL_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return DDRL_OK;
+}
+
+// rows [k0, k0 + n) of DZ <- D o z from the reference stream, then X rows = m + sigma * DZ * B^T
+static int sample_rows(ddrl_cmaes *h, int k0, int n) {
+  const int N = h->N;
+  std::vector<float> dz((size_t)n * h->ldn, 0.f);
+  for (int k = 0; k < n; ++k)
+    for (int i = 0; i < N; ++i) dz[(size_t)k * h->ldn + i] = (float)(h->D[i] * rnd_gauss(h));   // cmaes.c:645
+  HIPCHK(hipMemcpyAsync(h->d_DZ + (size_t)k0 * h->ldn, dz.data(), dz.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  dim3 grid((N + 63) / 64, (n + 63) / 64);
+  hipLaunchKernelGGL(cmaes_gemm_nt<0>, grid, dim3(256), 0, h->stream, h->d_DZ + (size_t)k0 * h->ldn, h->ldn, h->d_B, h->ldn,
+                     h->d_X + (size_t)k0 * h->ldn, h->ldn, n, N, h->ldn, h->d_xmean, h->d_sc, 0., 0., 0., -1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));   // dz is a local buffer
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_sample(ddrl_cmaes_t *h) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = update_eigensystem(h);
+  if (rc) return rc;
+  if ((rc = sample_rows(h, 0, h->lambda))) return rc;
+  if (h->state == 3 || h->gen == 0) h->gen += 1;   // cmaes.c:654-656
+  h->state = 1;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_resample(ddrl_cmaes_t *h, int k) {
+  if (!h || k < 0 || k >= h->lambda) return ddrl_fail(DDRL_EINVAL, "index==%d must be between 0 and %d", k, h ? h->lambda : 0);
+  HIPCHK(hipSetDevice(h->device));
+  return sample_rows(h, k, 1);
+}
+
+extern "C" int ddrl_cmaes_make_feasible(ddrl_cmaes_t *h, double bound, int *n_resampled) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  int count = 0;
+  std::vector<int> flag(h->lambda);
+  auto check = [&]() -> int {
+    hipLaunchKernelGGL(cmaes_infeasible_kernel, dim3(h->lambda), dim3(256), 0, h->stream, h->d_X, h->ldn, h->N, (float)bound, h->d_flag);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(flag.data(), h->d_flag, h->lambda * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DDRL_OK;
+  };
+  int rc = check();
+  if (rc) return rc;
+  for (int i = 0; i < h->lambda; ++i) {          // CMAESAg.hpp:163-167: in index order, until feasible
+    while (flag[i]) {
+      if ((rc = sample_rows(h, i, 1))) return rc;
+      ++count;
+      if (count > 100000) return ddrl_fail(DDRL_ESTATE, "feasibility resampling does not terminate");
+      if ((rc = check())) return rc;
+    }
+  }
+  if (n_resampled) *n_resampled = count;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_get_population(ddrl_cmaes_t *h, double *X) {
+  if (!h || !X) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<float> xf((size_t)h->lambda * h->ldn);
+  HIPCHK(hipMemcpyAsync(xf.data(), h->d_X, xf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < h->lambda; ++k)
+    for (int i = 0; i < h->N; ++i) X[(size_t)k * h->N + i] = xf[(size_t)k * h->ldn + i];
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_population_dev(ddrl_cmaes_t *h, const float **d_X, int *ld) {
+  if (!h || !d_X || !ld) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  *d_X = h->d_X;
+  *ld = h->ldn;
+  return DDRL_OK;
+}
+
+static int rank_dev(ddrl_cmaes *h, const double *d_f, int n, int *d_index) {
+  int p2 = 2;
+  while (p2 < n) p2 <<= 1;
+  const size_t lds = (size_t)p2 * (sizeof(unsigned long long) + sizeof(unsigned int));
+  static size_t configured = 0;
+  if (lds > 48 * 1024 && lds > configured) {
+    HIPCHK(hipFuncSetAttribute((const void *)cmaes_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  hipLaunchKernelGGL(cmaes_rank_kernel, dim3(1), dim3(1024), lds, h->stream, d_f, n, p2, d_index);
+  HIPCHK(hipGetLastError());
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_rank(ddrl_cmaes_t *h, const double *fitness, int n, int32_t *index_out) {
+  if (!h || !fitness || !index_out || n < 1 || n > h->lambda) return ddrl_fail(DDRL_EINVAL, "bad argument (n must be 1..lambda)");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_fit, fitness, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = rank_dev(h, h->d_fit, n, h->d_flag);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(index_out, h->d_flag, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_update_dev(ddrl_cmaes_t *h, const double *d_fitness) {
+  if (!h || !d_fitness) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  if (h->state != 1) return ddrl_fail(DDRL_ESTATE, "cmaes_UpdateDistribution(): call ddrl_cmaes_sample() before the update");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N;
+  h->countevals += h->lambda;
+  if (d_fitness != h->d_fit)
+    HIPCHK(hipMemcpyAsync(h->d_fit, d_fitness, h->lambda * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  int rc = rank_dev(h, h->d_fit, h->lambda, h->d_index);
+  if (rc) return rc;
+  CmaesVecArgs a;
+  a.N = N; a.ldx = h->ldn; a.ldn = h->ldn; a.lambda = h->lambda; a.mu = h->mu;
+  a.mueff = h->mueff; a.cs = h->cs; a.damps = h->damps; a.ccumcov = h->ccumcov; a.chiN = h->chiN; a.gen = h->gen;
+  a.X = h->d_X; a.B = h->d_B; a.fit = h->d_fit; a.index = h->d_index; a.weights = h->d_w;
+  a.xmean = h->d_xmean; a.xold = h->d_xold; a.ps = h->d_ps; a.pc = h->d_pc; a.BDz = h->d_BDz; a.tmp = h->d_tmp;
+  a.D = h->d_D; a.sc = h->d_sc; a.xbest = h->d_xbest;
+  hipLaunchKernelGGL(cmaes_vec_kernel, dim3(1), dim3(1024), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  // Adapt_C2 (cmaes.c:963-1001), diagonalCov == 0
+  if (h->ccov != 0.) {
+    const double ccov1 = std::min(h->ccov * (1. / h->mucov), 1.);
+    const double ccovmu = std::min(h->ccov * (1 - 1. / h->mucov), 1. - ccov1);
+    dim3 pg((h->mu16 + 255) / 256, N);
+    hipLaunchKernelGGL(cmaes_pack_y, pg, dim3(256), 0, h->stream, h->d_X, h->ldn, h->d_index, h->d_w, h->d_xold, h->d_sc,
+                       N, h->mu, h->mu16, h->d_Y);
+    HIPCHK(hipGetLastError());
+    dim3 grid((N + 63) / 64, (N + 63) / 64);
+    hipLaunchKernelGGL(cmaes_gemm_nt<1>, grid, dim3(256), 0, h->stream, h->d_Y, h->mu16, h->d_Y, h->mu16, h->d_C, h->ldn,
+                       N, N, h->mu16, h->d_pc, h->d_sc, ccov1, ccovmu, h->ccumcov, -1);
+    HIPCHK(hipGetLastError());
+    h->eigen_uptodate = 0;
+  }
+  h->state = 3;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_update(ddrl_cmaes_t *h, const double *fitness) {
+  if (!h || !fitness) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->d_fit, fitness, h->lambda * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ddrl_cmaes_update_dev(h, h->d_fit);
+}
+
+extern "C" int ddrl_cmaes_get(ddrl_cmaes_t *h, const char *key, double *out) {
+  if (!h || !key || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  const std::string k(key);
+  if (k == "sigma" || k == "fbestever") {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out, h->d_sc + (k == "sigma" ? SC_SIGMA : SC_FBEST), sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DDRL_OK;
+  }
+  if (k == "gen") *out = h->gen; else if (k == "lambda") *out = h->lambda; else if (k == "mu") *out = h->mu;
+  else if (k == "N" || k == "dim") *out = h->N; else if (k == "mueff") *out = h->mueff; else if (k == "cs") *out = h->cs;
+  else if (k == "damps") *out = h->damps; else if (k == "ccumcov") *out = h->ccumcov; else if (k == "ccov") *out = h->ccov;
+  else if (k == "mucov") *out = h->mucov; else if (k == "chiN") *out = h->chiN; else if (k == "modulo") *out = h->modulo;
+  else if (k == "eigen_uptodate") *out = h->eigen_uptodate; else if (k == "countevals") *out = h->countevals;
+  else return ddrl_fail(DDRL_EINVAL, "cmaes_Get: unknown key '%s'", key);
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_get_vec(ddrl_cmaes_t *h, const char *key, double *out) {
+  if (!h || !key || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  const std::string k(key);
+  const int N = h->N;
+  const double *src = nullptr;
+  if (k == "xmean") src = h->d_xmean; else if (k == "ps") src = h->d_ps; else if (k == "pc") src = h->d_pc;
+  else if (k == "D") src = h->d_D; else if (k == "xbestever") src = h->d_xbest;
+  if (src) {
+    HIPCHK(hipMemcpyAsync(out, src, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DDRL_OK;
+  }
+  if (k == "weights") { std::copy(h->weights.begin(), h->weights.end(), out); return DDRL_OK; }
+  if (k == "C" || k == "diagC" || k == "B") {
+    std::vector<float> M((size_t)N * h->ldn);
+    HIPCHK(hipMemcpyAsync(M.data(), k == "B" ? h->d_B : h->d_C, M.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (k == "diagC") for (int i = 0; i < N; ++i) out[i] = M[(size_t)i * h->ldn + i];
+    else for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) out[(size_t)i * N + j] = M[(size_t)i * h->ldn + j];
+    return DDRL_OK;
+  }
+  return ddrl_fail(DDRL_EINVAL, "cmaes_GetPtr: unknown key '%s'", key);
+}
+
+extern "C" int ddrl_cmaes_get_index(ddrl_cmaes_t *h, int32_t *index) {
+  if (!h || !index) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(index, h->d_index, h->lambda * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}

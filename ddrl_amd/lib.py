@@ -68,6 +68,19 @@ SYMBOLS = [
     ("ddrl_pop_profile_read", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     ("ddrl_pop_debug_stamps", _i, [_vp, _i, _vp]),
     ("ddrl_pop_set_option", _i, [_vp, _cp, _i]),
+    ("ddrl_cmaes_create", _i, [_i, _vp, _vp, C.c_long, _i, _i, C.POINTER(_vp)]),
+    ("ddrl_cmaes_destroy", _i, [_vp]),
+    ("ddrl_cmaes_sample", _i, [_vp]),
+    ("ddrl_cmaes_resample", _i, [_vp, _i]),
+    ("ddrl_cmaes_make_feasible", _i, [_vp, C.c_double, C.POINTER(_i)]),
+    ("ddrl_cmaes_get_population", _i, [_vp, _vp]),
+    ("ddrl_cmaes_population_dev", _i, [_vp, C.POINTER(_vp), C.POINTER(_i)]),
+    ("ddrl_cmaes_update", _i, [_vp, _vp]),
+    ("ddrl_cmaes_update_dev", _i, [_vp, _vp]),
+    ("ddrl_cmaes_rank", _i, [_vp, _vp, _i, _vp]),
+    ("ddrl_cmaes_get", _i, [_vp, _cp, C.POINTER(C.c_double)]),
+    ("ddrl_cmaes_get_vec", _i, [_vp, _cp, _vp]),
+    ("ddrl_cmaes_get_index", _i, [_vp, _vp]),
 ]
 
 _lib = None

@@ -137,6 +137,50 @@ int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost /* [G] */);
 int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat, double *wstar,
                      double *fisher_nbr /* [G] */, double *decay_mult /* [G] */);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * CMA-ES policy search (agent/cmaes): the vendored c-cmaes (agent/cmaes/src/cmaes.c) as driven by
+ * CMAESAg (agent/cmaes/include/CMAESAg.hpp).  Population X [lambda x N], B, C live on the GPU in
+ * fp32; sampling x = m + sigma * B (D o z) and the rank-mu covariance update are fp32-MFMA GEMMs,
+ * ranking is an exact sort with c-cmaes' tie rule; the N-vectors (mean, ps, pc, D) and scalars are
+ * fp64 on the device; the lazily scheduled eigendecomposition (cmaes.c:1885-1947) runs on the host
+ * in fp64.  z comes from the reference's own generator (cmaes.c:2421-2482, sequential by
+ * construction) evaluated on the host, so runs are reproducible against c-cmaes seed for seed.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ddrl_cmaes ddrl_cmaes_t;
+
+/* cmaes_init(evo, N, xstart, stds, seed, lambda, "non") (cmaes.c:404-415; CMAESAg.hpp:97-98).
+ * seed must be >= 1 (the reference's seed 0 means "seed from the clock", cmaes.c:2406-2410);
+ * lambda < 2 selects the default 4 + floor(3 ln N) (cmaes.c:2795-2796). */
+int ddrl_cmaes_create(int N, const double *xstart, const double *stds, long seed, int lambda, int device,
+                      ddrl_cmaes_t **out);
+int ddrl_cmaes_destroy(ddrl_cmaes_t *h);
+/* cmaes_SamplePopulation (cmaes.c:612-659) */
+int ddrl_cmaes_sample(ddrl_cmaes_t *h);
+/* cmaes_ReSampleSingle (cmaes.c:685-708) */
+int ddrl_cmaes_resample(ddrl_cmaes_t *h, int k);
+/* CMAESAg::new_population's feasibility loop (CMAESAg.hpp:135-171): individuals with any
+ * |x_i| >= bound are resampled one at a time in index order; *n_resampled (may be NULL) counts */
+int ddrl_cmaes_make_feasible(ddrl_cmaes_t *h, double bound, int *n_resampled);
+/* the sampled population, [lambda x N] row-major: host copy (double) / device pointer (fp32, row
+ * stride *ld floats) for loading individuals into a policy population without leaving the GPU */
+int ddrl_cmaes_get_population(ddrl_cmaes_t *h, double *X);
+int ddrl_cmaes_population_dev(ddrl_cmaes_t *h, const float **d_X, int *ld);
+/* cmaes_UpdateDistribution (cmaes.c:797-958) + Adapt_C2 (cmaes.c:963-1001).  fitness [lambda] is
+ * double like c-cmaes' rgFunVal (CMAESAg.hpp:239,354) and is ranked in fp64.  _dev: device pointer
+ * (e.g. the result of the RCCL fitness all-gather). */
+int ddrl_cmaes_update(ddrl_cmaes_t *h, const double *fitness);
+int ddrl_cmaes_update_dev(ddrl_cmaes_t *h, const double *d_fitness);
+/* Sorted_index (cmaes.c:2989-3000) on the GPU: ascending, equal values => later index first */
+int ddrl_cmaes_rank(ddrl_cmaes_t *h, const double *fitness, int n, int32_t *index_out);
+/* cmaes_Get (scalars: "sigma","gen","lambda","mu","N","mueff","cs","damps","ccumcov","ccov","mucov",
+ * "chiN","modulo","eigen_uptodate","countevals","fbestever") and cmaes_GetPtr-like vectors ("xmean",
+ * "xbestever" (CMAESAg::getBestSolution, CMAESAg.hpp:328-335),"ps","pc","D",
+ * "weights" [mu],"diagC","C" [N x N],"B" [N x N]) */
+int ddrl_cmaes_get(ddrl_cmaes_t *h, const char *key, double *out);
+int ddrl_cmaes_get_vec(ddrl_cmaes_t *h, const char *key, double *out);
+int ddrl_cmaes_get_index(ddrl_cmaes_t *h, int32_t *index /* [lambda] */);
+
 /* Measurement hooks (no counterpart in the reference, which only records total wall minutes,
  * common/include/arch/Simulator.hpp:127): with profiling on, every ddrl_pop_ddpg_update() brackets
  * its update kernel with HIP events on the handle's stream; ddrl_pop_profile_read() synchronises and

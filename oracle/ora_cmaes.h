@@ -17,6 +17,8 @@ int    ora_cmaes_get_int(const ora_cmaes *t, const char *key);
 double ora_cmaes_get(const ora_cmaes *t, const char *key);
 const double *ora_cmaes_ptr(const ora_cmaes *t, const char *key);
 const int *ora_cmaes_index(const ora_cmaes *t);
+/* test hook (teacher forcing: resync the oracle to the device's fp32-rounded state between steps) */
+void   ora_cmaes_set_sigma(ora_cmaes *t, double sigma);
 #ifdef __cplusplus
 }
 #endif

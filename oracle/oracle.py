@@ -136,6 +136,7 @@ def lib():
     L.ora_cmaes_ptr.argtypes = [vp, C.c_char_p]
     L.ora_cmaes_index.restype = C.POINTER(C.c_int)
     L.ora_cmaes_index.argtypes = [vp]
+    L.ora_cmaes_set_sigma.argtypes = [vp, C.c_double]
     _lib = L
     return L
 
@@ -397,6 +398,14 @@ class Cmaes:
         n = self.N if n is None else n
         p = lib().ora_cmaes_ptr(self.h, key.encode())
         return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+    def view(self, key, n=None):
+        """writable view of the oracle's own array (teacher forcing in the GPU parity tests)"""
+        n = self.N if n is None else n
+        return np.ctypeslib.as_array(lib().ora_cmaes_ptr(self.h, key.encode()), shape=(n,))
+
+    def set_sigma(self, sigma):
+        lib().ora_cmaes_set_sigma(self.h, float(sigma))
 
     def index(self):
         return np.ctypeslib.as_array(lib().ora_cmaes_index(self.h), shape=(self.lam,)).copy()
