@@ -11,7 +11,7 @@
 // The kernel is a template over the two net shapes.  Instantiated on SNet<...> (compile-time
 // shapes: the BASELINE "mid" and "small" HalfCheetah nets) every loop bound and guard is a
 // constant; instantiated on NetDesc it is the generic kernel for any shape up to DDRL_MAXW.
-#include "mlp_device.h"
+#include "net_device.h"
 
 struct LdsMap {
   float *hbase; int hstride; // hidden activation l (1..L-1) of the pass in flight lives at hbase + (l-1)*hstride
@@ -19,87 +19,6 @@ struct LdsMap {
   float *topq, *topa;        // output tiles: q [64 x 4], actions [64 x ld(A)]
   float *yv, *rv, *dn;       // TD target, reward, goal flag per row
 };
-
-// forward through layers [0, nl) of a net; hidden activation l goes to hbase + (l-1)*hstride, the
-// output of the last InnerProduct (when nl == L) to top
-template <class ND>
-__device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__restrict__ w,
-                                        const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
-                                        int wave, int lane) {
-  const float *in = X;
-  int ldi = ldx;
-  BFrag b0;
-  bool have = false;
-#pragma unroll
-  for (int l = 0; l < nd.L(); ++l) {
-    if (l < nl) {
-      const bool last = l == nd.L() - 1;
-      const bool more = l + 1 < nl;
-      const int ln = more ? l + 1 : l;       // keeps the accessors in range when there is no next layer
-      float *out = last ? top : hbase + l * hstride;
-      const int ldo = last ? ldtop : nd.ld(l + 1);
-      fwd_layer(in, ldi, nd.kp(l), w + nd.offw(l), w + nd.offb(l), nd.d(l + 1),
-                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane, b0, have,
-                more ? w + nd.offw(ln) : nullptr, more ? nd.kp(ln) : 0, more ? nd.d(ln + 1) : 0);
-      __syncthreads();
-      in = out;
-      ldi = ldo;
-    }
-  }
-}
-
-// Backward through a whole net from dZ_L held in `top` (diff w.r.t. the last InnerProduct's
-// output).  TRAIN: parameter gradients go through the fused optimiser epilogue.  nc > 0: the input
-// gradient columns [c0, c0 + nc) are handed to dx0_store(row, col - c0, value).
-template <bool TRAIN, bool EWC, class ND, class DX0>
-__device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w, const OptCtx opt,
-                                        const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
-                                        int c0, int nc, DX0 dx0_store, int wave, int lane, int tid) {
-  const int g = lane >> 4, c = lane & 15;
-  float *dZ = top;
-  int ldz = ldtop;
-#pragma unroll
-  for (int ll = 0; ll < nd.L(); ++ll) {
-    const int l = nd.L() - 1 - ll;
-    const int K = nd.d(l), N = nd.d(l + 1), kp = nd.kp(l);
-    const float *W = w + nd.offw(l);
-    float *in = l == 0 ? const_cast<float *>(X) : hbase + (l - 1) * hstride;
-    const int ldi = l == 0 ? ldx : nd.ld(l);
-    const bool need_dx = l > 0 || nc > 0;
-    f32x4 acc[DDRL_MAXKT][4];
-    int kt0 = 0, kt1 = (K + 15) >> 4;
-    if (l == 0) { kt0 = c0 >> 4; kt1 = (c0 + nc + 15) >> 4; }
-    if (need_dx) bwd_dx<DDRL_MAXKT>(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
-    if (TRAIN) {
-      __syncthreads();   // every wave has read W_l before any wave's epilogue rewrites it
-      bwd_dw_opt<EWC, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
-    }
-    __syncthreads();     // every wave has read H_l before it is overwritten by dZ_l
-    if (need_dx) {
-#pragma unroll
-      for (int i = 0; i < DDRL_MAXKT; ++i) {
-        const int kt = kt0 + wave + DDRL_NWAVES * i;
-        if (kt < kt1) {
-          const int col = kt * 16 + c;
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = mt * 16 + 4 * g + r;
-              if (l > 0) {
-                if (col < K) in[row * ldi + col] = act_bwd(nd.hidden_act(), in[row * ldi + col], acc[i][mt][r]);
-              } else if (col >= c0 && col < c0 + nc) {
-                dx0_store(row, col - c0, acc[i][mt][r]);
-              }
-            }
-        }
-      }
-      __syncthreads();
-    }
-    dZ = in;
-    ldz = ldi;
-  }
-}
 
 // gather one 64-row tile of the minibatch from the agent's replay ring (DeepQNAg.hpp:353-377,
 // nstep_return == 0).  next=true: s' into xa and xc[:, :S];  next=false: s into xa, [s|a] into xc,
@@ -156,10 +75,6 @@ __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &
   o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
   return o;
 }
-
-// run-time descriptors live in the kernel arguments; compile-time ones are empty tag objects
-template <class ND> struct Pick { static __device__ __forceinline__ ND get(const NetDesc &) { return ND(); } };
-template <> struct Pick<NetDesc> { static __device__ __forceinline__ const NetDesc &get(const NetDesc &n) { return n; } };
 
 template <class NA, class NQ, bool EWC_A, bool EWC_Q>
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU
@@ -235,7 +150,7 @@ ddpg_update_kernel(const DdpgParams P) {
   auto none = [](int, int, float) {};
   {
     const OptCtx oq = make_opt<EWC_Q>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B);
-    bwd_net<true, EWC_Q>(nq, w_q, oq, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid);
+    bwd_net<DW_OPT, EWC_Q>(nq, w_q, oq, nullptr, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid);
   }
   STAMP(5);
 
@@ -266,7 +181,7 @@ ddpg_update_kernel(const DdpgParams P) {
       topa[row * lda + h] = act_bwd(out_act, out, diff);                 // actor's output layer, in place
     };
     OptCtx unused = {};
-    bwd_net<false, false>(nq, w_q, unused, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, S, A, store, wave, lane, tid);
+    bwd_net<DW_NONE, false>(nq, w_q, unused, nullptr, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, S, A, store, wave, lane, tid);
   }
   STAMP(8);
   // the actor's hidden activations shared their LDS with the critic pass: recompute them (one extra
@@ -275,7 +190,7 @@ ddpg_update_kernel(const DdpgParams P) {
   STAMP(9);
   {
     const OptCtx oa = make_opt<EWC_A>(P, P.sa, na.stride(), agent, tau, omtau, (float)B);  // updateFisher(traj.size()) :456
-    bwd_net<true, EWC_A>(na, w_a, oa, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, 0, 0, none, wave, lane, tid);
+    bwd_net<DW_OPT, EWC_A>(na, w_a, oa, nullptr, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, 0, 0, none, wave, lane, tid);
   }
   STAMP(10);
   if (tid == 0) {

@@ -1,0 +1,308 @@
+// kernels_nfac.hip -- NFAC(lambda)-V on gfx950: the arithmetic of OfflineCaclaAg::update_critic and
+// ::end_episode (/root/reference/agent/cacla/include/OfflineCaclaAg.hpp:242-401, 423-594) for a
+// population of agents.  The batch of every Adam step is the agent's WHOLE trajectory (T rows,
+// MLP::increase_batchsize, MLP.hpp:403-435), so one step is split over 64-row chunks:
+//
+//   nfac_values_kernel   V(s), V(s')  per row                       grid (chunks, G)
+//   nfac_scan_kernel     TD targets / lambda-return backward scan   grid (G)
+//                        (:268-348) or advantages + CACLA selection (:464-522)
+//   nfac_grad_kernel     forward + backward of one chunk, partial dW to gpart   grid (chunks, G)
+//   nfac_apply_kernel    fixed-order reduction of the partials, Fisher EMA, EWC penalty, Adam
+//                        (MLP::learn_batch's loop body, MLP.hpp:476-483)        grid (stride/1024, G)
+//
+// Weights are read from L2 by the MFMA products (same blocks as the DDPG kernel, net_device.h);
+// the reduction order over chunks is fixed, so results are deterministic.
+#include "net_device.h"
+
+struct NfacLds { float *hbase; int hstride; float *x, *top; };
+
+__device__ __forceinline__ NfacLds nfac_carve(float *lds, const NetDesc &nd, int ldh) {
+  NfacLds M;
+  float *p = lds;
+  M.hbase = p; M.hstride = DDRL_MB * ldh; p += (nd.L() - 1) * M.hstride;
+  M.x = p; p += DDRL_MB * nd.ld(0);
+  M.top = p;
+  return M;
+}
+static size_t nfac_lds_bytes(const NetDesc &nd, int ldh) {
+  return ((size_t)(nd.L_ - 1) * DDRL_MB * ldh + (size_t)DDRL_MB * (nd.ld_[0] + nd.ld_[nd.L_])) * sizeof(float);
+}
+
+// 64 rows [row0, row0 + 64) of the state columns starting at `col0` of the trajectory into Xs
+__device__ __forceinline__ void load_states(const float *__restrict__ traj, int rowlen, int T, int row0, int col0,
+                                            int S, int ldx, float *Xs, int tid) {
+  for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
+    const int row = e / ldx, col = e - row * ldx;
+    Xs[e] = (row0 + row < T && col < S) ? traj[(size_t)(row0 + row) * rowlen + col0 + col] : 0.f;
+  }
+}
+
+// all_nextV = vnn(s'), all_V = vnn(s)   (OfflineCaclaAg.hpp:266,315 / :460-461)
+__global__ void __launch_bounds__(DDRL_NTHREADS)
+nfac_values_kernel(const NfacParams P) {
+  extern __shared__ __align__(16) float lds[];
+  const int chunk = blockIdx.x, agent = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (P.mask && !P.mask[agent]) return;
+  const int T = P.len[agent], row0 = chunk * DDRL_MB;
+  if (row0 >= T) return;
+  const NetDesc &nv = P.v;
+  const NfacLds M = nfac_carve(lds, nv, P.ldh);
+  const int ldx = nv.ld(0), ldt = nv.ld(nv.L());
+  const float *traj = P.traj + (size_t)agent * P.maxT * P.rowlen;
+  const float *w = P.sv.w + (size_t)agent * nv.stride();
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    load_states(traj, P.rowlen, T, row0, pass == 0 ? 0 : P.S + 2 * P.A, P.S, ldx, M.x, tid);
+    __syncthreads();
+    fwd_net(nv, nv.L(), w, M.x, ldx, M.hbase, M.hstride, M.top, ldt, wave, lane);
+    float *out = (pass == 0 ? P.V : P.nextV) + (size_t)agent * P.maxT;
+    if (tid < DDRL_MB && row0 + tid < T) out[row0 + tid] = M.top[tid * ldt];
+    __syncthreads();
+  }
+}
+
+// MODE 0, update_critic (OfflineCaclaAg.hpp:268-348): v_target = r + gamma V(s') (1 - goal);
+//   lambda < 0: tgt = v_target; else deltas = v_target - V, backward scan
+//   diff_t = delta_t + gamma lambda diff_{t+1} restarted at every episode's last row, tgt = diff + V.
+// MODE 1, end_episode (:464-522): deltas (through the same scan when gae), n = #(delta > 0), and the
+//   CACLA row selection.
+// The scan runs sequentially in the reference's order from LDS.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+nfac_scan_kernel(const NfacParams P) {
+  extern __shared__ __align__(16) float sd[];      // [T] deltas
+  const int agent = blockIdx.x, tid = threadIdx.x;
+  if (P.mask && !P.mask[agent]) return;
+  const int T = P.len[agent];
+  if (T <= 0) { if (MODE == 1 && tid == 0) P.n_pos[agent] = 0; return; }
+  const size_t ro = (size_t)agent * P.maxT;
+  const float *traj = P.traj + ro * P.rowlen;
+  const float gamma = P.gamma[agent];
+  const int cr = 2 * P.S + 2 * P.A;
+  const bool scan = MODE == 0 ? P.lambda >= 0.f : P.gae != 0;
+  for (int li = tid; li < T; li += 256) {
+    const float *row = traj + (size_t)li * P.rowlen;
+    float vt = row[cr];
+    if (row[cr + 1] == 0.f) vt += gamma * P.nextV[ro + li];
+    sd[li] = (MODE == 0 && P.lambda < 0.f) ? vt : vt - P.V[ro + li];
+  }
+  __syncthreads();
+  if (scan && tid == 0) {
+    const float gl = gamma * P.lambda;
+    const uint8_t *ef = P.endflag + ro;
+    float prev = 0.f;
+    for (int li = T - 1; li >= 0; --li) {
+      if (ef[li]) prev = 0.f;
+      const float d = sd[li] + prev;
+      sd[li] = d;
+      prev = gl * d;
+    }
+  }
+  __syncthreads();
+  int n = 0;
+  for (int li = tid; li < T; li += 256) {
+    const float d = sd[li];
+    if (MODE == 0) {
+      P.tgt[ro + li] = P.lambda < 0.f ? d : d + P.V[ro + li];
+    } else {
+      P.deltas[ro + li] = d;
+      uint8_t mode;
+      if (d > 0.f) { mode = 1; ++n; }
+      else mode = P.update_delta_neg ? 2 : 0;
+      P.rowmode[ro + li] = mode;
+    }
+  }
+  if (MODE == 1) {
+    __shared__ int cnt[256];
+    cnt[tid] = n;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) cnt[tid] += cnt[tid + s]; __syncthreads(); }
+    if (tid == 0) P.n_pos[agent] = cnt[0];
+  }
+}
+
+// One chunk of one full-batch gradient.  MODE 0: critic, EuclideanLoss against tgt (MLP.hpp:950-957:
+// d yhat = (yhat - y) / T).  MODE 1: actor, top diff = -(target - pi(s)) on the selected rows with
+// optional inverting gradient (OfflineCaclaAg.hpp:531-566), no 1/T.
+template <int MODE>
+__global__ void __launch_bounds__(DDRL_NTHREADS)
+nfac_grad_kernel(const NfacParams P) {
+  extern __shared__ __align__(16) float lds[];
+  const int chunk = blockIdx.x, agent = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (P.mask && !P.mask[agent]) return;
+  const int T = P.len[agent], row0 = chunk * DDRL_MB;
+  if (row0 >= T) return;
+  if (MODE == 1 && P.n_pos[agent] <= 0) return;
+  const NetDesc &nd = MODE == 0 ? P.v : P.a;
+  const NetState &st = MODE == 0 ? P.sv : P.sa;
+  const NfacLds M = nfac_carve(lds, nd, P.ldh);
+  const int ldx = nd.ld(0), ldt = nd.ld(nd.L());
+  const size_t ro = (size_t)agent * P.maxT;
+  const float *traj = P.traj + ro * P.rowlen;
+  const float *w = st.w + (size_t)agent * nd.stride();
+  load_states(traj, P.rowlen, T, row0, 0, P.S, ldx, M.x, tid);
+  __syncthreads();
+  fwd_net(nd, nd.L(), w, M.x, ldx, M.hbase, M.hstride, M.top, ldt, wave, lane);
+  if (MODE == 0) {
+    if (tid < DDRL_MB) {
+      const int li = row0 + tid;
+      const float df = li < T ? M.top[tid * ldt] - P.tgt[ro + li] : 0.f;
+      float sq = df * df;
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+      if (tid == 0) P.loss_part[(size_t)agent * P.maxchunks + chunk] = sq;
+      M.top[tid * ldt] = df / (float)T;
+    }
+  } else {
+    const int A = P.A;
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+      const int row = e / A, h = e - row * A, li = row0 + row;
+      const float out = M.top[row * ldt + h];
+      float diff = 0.f;
+      const int mode = li < T ? P.rowmode[ro + li] : 0;
+      if (mode) {
+        const float target = traj[(size_t)li * P.rowlen + P.S + (mode == 1 ? A : 0) + h];
+        diff = -(target - out);
+        if (P.inverting) {
+          if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
+          else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
+        }
+      }
+      M.top[row * ldt + h] = act_bwd(nd.out_act(), out, diff);     // the actor's output layer, in place
+    }
+  }
+  __syncthreads();
+  auto none = [](int, int, float) {};
+  OptCtx unused = {};
+  float *gout = (MODE == 0 ? P.gpart_v : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
+  bwd_net<DW_STORE, false>(nd, w, unused, gout, M.x, ldx, M.hbase, M.hstride, M.top, ldt, 0, 0, none, wave, lane, tid);
+}
+
+// Sum of the chunk partials in chunk order, then updateFisher(nsample) / regularize() /
+// ApplyUpdate() / set_iter(iter + 1) (MLP.hpp:479-482; OfflineCaclaAg.hpp:567-570) on 4 parameters
+// per thread.  iter_add: Adam steps already applied during this update (iter itself is bumped once
+// at the end by nfac_finish_kernel).
+template <int MODE, bool EWC>
+__global__ void __launch_bounds__(256)
+nfac_apply_kernel(const NfacParams P, int iter_add, int last) {
+  const int agent = blockIdx.y, tid = threadIdx.x;
+  if (P.mask && !P.mask[agent]) return;
+  const int T = P.len[agent];
+  if (T <= 0) return;
+  const int npos = MODE == 1 ? P.n_pos[agent] : 1;
+  if (npos <= 0) return;
+  const NetDesc &nd = MODE == 0 ? P.v : P.a;
+  const NetState &st = MODE == 0 ? P.sv : P.sa;
+  const int nch = (T + DDRL_MB - 1) / DDRL_MB;
+  __shared__ float s_lrt;
+  if (tid == 0) {
+    const int t = st.iter[agent] + iter_add + 1;
+    const double corr = sqrt(1.0 - pow(P.dbeta2, (double)t)) / (1.0 - pow(P.dbeta1, (double)t));
+    s_lrt = (float)((double)st.lr[agent] * corr);
+  }
+  __syncthreads();
+  const float nsample = MODE == 0 ? (float)T : (float)npos;
+  OptCtx o;
+  const size_t off = (size_t)agent * nd.stride();
+  o.w = st.w + off; o.m = st.m + off; o.v = st.v + off; o.wt = nullptr;
+  o.fisher = EWC ? st.fisher + off : nullptr;
+  o.fhat = EWC ? st.fhat + off : nullptr;
+  o.wstar = EWC ? st.wstar + off : nullptr;
+  o.lr_t = s_lrt; o.tau = 0.f; o.omtau = 0.f;
+  o.decay = -1.f;                                  // OfflineCaclaAg.hpp:186,190: no weight decay
+  o.ewc_coef = EWC ? st.ewc_coef[agent] : 0.f;
+  o.fisher_beta = P.fisher_beta; o.nsample = nsample;
+  o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
+  const int i = (blockIdx.x * 256 + tid) * 4;
+  if (i < nd.stride()) {
+    OptRegs r;
+    opt_load4<EWC, false>(o, i, r);
+    const float *gp = (MODE == 0 ? P.gpart_v : P.gpart_a) + (size_t)agent * P.maxchunks * nd.stride() + i;
+    f32x4 g = *(const f32x4 *)gp;
+    for (int c = 1; c < nch; ++c) g += *(const f32x4 *)(gp + (size_t)c * nd.stride());
+    opt_step4<EWC, false>(o, i, g, r, true);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    if (EWC) st.fisher_nbr[agent] = st.fisher_nbr[agent] * P.fisher_beta + nsample;   // DODevMLP.hpp:655
+    if (MODE == 0 && last) {
+      float s = 0.f;
+      for (int c = 0; c < nch; ++c) s += P.loss_part[(size_t)agent * P.maxchunks + c];
+      P.loss_out[agent] = s / (float)T * 0.5f;
+    }
+  }
+}
+
+// Solver::iter after the update: + number_fitted_iteration * stoch_iter_critic for the critic,
+// + stoch_iter_actor for the actor when at least one transition had a positive advantage
+__global__ void nfac_finish_kernel(const NfacParams P, int critic_steps, int actor_steps) {
+  const int agent = blockIdx.x * blockDim.x + threadIdx.x;
+  if (agent >= P.G) return;
+  if (P.mask && !P.mask[agent]) return;
+  if (P.len[agent] <= 0) return;
+  P.sv.iter[agent] += critic_steps;
+  if (P.n_pos[agent] > 0) P.sa.iter[agent] += actor_steps;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <class K>
+static hipError_t set_lds(K kernel, size_t lds, size_t &configured) {
+  if (lds > 48 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  return hipSuccess;
+}
+
+extern "C" size_t nfac_lds_need(const NfacParams *P) {
+  return std::max(nfac_lds_bytes(P->a, P->ldh), nfac_lds_bytes(P->v, P->ldh));
+}
+
+extern "C" hipError_t nfac_values_launch(const NfacParams *P, int chunks, hipStream_t st) {
+  static size_t conf = 0;
+  const size_t lds = nfac_lds_bytes(P->v, P->ldh);
+  hipError_t e = set_lds(nfac_values_kernel, lds, conf);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(nfac_values_kernel, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen, hipStream_t st) {
+  static size_t conf0 = 0, conf1 = 0;
+  const size_t lds = (size_t)std::max(maxlen, 1) * sizeof(float);
+  hipError_t e = mode == 0 ? set_lds(nfac_scan_kernel<0>, lds, conf0) : set_lds(nfac_scan_kernel<1>, lds, conf1);
+  if (e != hipSuccess) return e;
+  if (mode == 0) hipLaunchKernelGGL(nfac_scan_kernel<0>, dim3(P->G), dim3(256), lds, st, *P);
+  else hipLaunchKernelGGL(nfac_scan_kernel<1>, dim3(P->G), dim3(256), lds, st, *P);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, hipStream_t st) {
+  static size_t conf0 = 0, conf1 = 0;
+  const size_t lds = nfac_lds_bytes(mode == 0 ? P->v : P->a, P->ldh);
+  hipError_t e = mode == 0 ? set_lds(nfac_grad_kernel<0>, lds, conf0) : set_lds(nfac_grad_kernel<1>, lds, conf1);
+  if (e != hipSuccess) return e;
+  if (mode == 0) hipLaunchKernelGGL(nfac_grad_kernel<0>, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  else hipLaunchKernelGGL(nfac_grad_kernel<1>, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nfac_apply_launch(const NfacParams *P, int mode, int iter_add, int last, hipStream_t st) {
+  const NetDesc &nd = mode == 0 ? P->v : P->a;
+  const bool ewc = (mode == 0 ? P->sv : P->sa).fisher != nullptr;
+  const dim3 grid((nd.stride_ + 1023) / 1024, P->G);
+  if (mode == 0) {
+    if (ewc) hipLaunchKernelGGL((nfac_apply_kernel<0, true>), grid, dim3(256), 0, st, *P, iter_add, last);
+    else hipLaunchKernelGGL((nfac_apply_kernel<0, false>), grid, dim3(256), 0, st, *P, iter_add, last);
+  } else {
+    if (ewc) hipLaunchKernelGGL((nfac_apply_kernel<1, true>), grid, dim3(256), 0, st, *P, iter_add, last);
+    else hipLaunchKernelGGL((nfac_apply_kernel<1, false>), grid, dim3(256), 0, st, *P, iter_add, last);
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nfac_finish_launch(const NfacParams *P, int critic_steps, int actor_steps, hipStream_t st) {
+  hipLaunchKernelGGL(nfac_finish_kernel, dim3((P->G + 255) / 256), dim3(256), 0, st, *P, critic_steps, actor_steps);
+  return hipGetLastError();
+}

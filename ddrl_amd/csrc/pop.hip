@@ -1,18 +1,7 @@
 // pop.hip -- host side of libddrl_pop.so: handle, device memory, the C ABI of include/ddrl_pop.h.
 // All arithmetic of the hot path runs in the gfx950 kernels (kernels_*.hip); there is no CPU
 // fallback: without a HIP device every create call fails with DDRL_EHIP.
-#include "../../include/ddrl_pop.h"
-#include "pop_internal.h"
-#include "host_util.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <limits>
-#include <random>
-#include <string>
-#include <vector>
+#include "pop_host.h"
 
 extern "C" {
 hipError_t ddpg_update_launch(const DdpgParams *P, int force_generic, hipStream_t st);
@@ -32,162 +21,6 @@ hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fi
                             int stride, const uint8_t *flag, int G, hipStream_t st);
 hipError_t ewc_cost_launch(const float *w, const float *wstar, const float *fhat, int stride, float *out, int G,
                            hipStream_t st);
-}
-
-// ---------------------------------------------------------------------------------------------
-// per-net host bookkeeping of the EWC life-cycle (DODevMLP.hpp:803-822)
-struct EwcHost {
-  bool enabled = false;
-  std::vector<double> best_score, decay_mult;
-  std::vector<int> last_update_best;
-  std::vector<uint8_t> best_valid, live;
-};
-
-struct TrainNet {
-  NetDesc nd;
-  NetState st;           // device pointers
-  EwcHost ewc;
-  float *d_lr = nullptr, *d_decay = nullptr;
-};
-
-struct ddrl_pop {
-  ddrl_ddpg_config cfg;
-  int G = 0, device = 0;
-  hipStream_t stream = nullptr;
-  TrainNet net[2];                 // 0 actor, 1 critic  (targets hang off st.wt)
-  // replay
-  int rowlen = 0;
-  float *d_rep = nullptr;
-  int *d_len = nullptr, *d_head = nullptr;
-  std::vector<int> h_len, h_head;
-  uint32_t *d_mt = nullptr;
-  int *d_mtpos = nullptr;
-  int *d_idx = nullptr;
-  // hyper
-  float *d_tau = nullptr, *d_omtau = nullptr, *d_gamma = nullptr;
-  // diagnostics
-  float *d_loss = nullptr, *d_qt = nullptr, *d_dact = nullptr;
-  long long *d_stamps = nullptr;
-  // staging
-  float *d_s = nullptr, *d_a = nullptr, *d_r = nullptr, *d_s2 = nullptr, *d_act = nullptr, *d_cost = nullptr;
-  uint8_t *d_goal = nullptr, *d_mask = nullptr, *d_flag = nullptr;
-  std::vector<void *> allocs;
-  DdpgParams P;
-  // measurement
-  bool profiling = false;
-  int force_generic = 0;
-  double beta1 = 0., beta2 = 0.999;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-  size_t ev_used = 0;
-};
-
-#define HIPCHK(expr)                                                                        \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess) return ddrl_fail(DDRL_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-template <class T>
-static int dalloc(ddrl_pop *h, T **p, size_t n, bool zero = true) {
-  void *q = nullptr;
-  hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
-  if (e != hipSuccess) return ddrl_fail(DDRL_ENOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
-  h->allocs.push_back(q);
-  if (zero) {
-    e = hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream);
-    if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "hipMemset: %s", hipGetErrorString(e));
-  }
-  *p = (T *)q;
-  return DDRL_OK;
-}
-
-static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout, int hidden_act, int out_act) {
-  memset(&nd, 0, sizeof(nd));
-  nd.L_ = nh + 1;
-  nd.d_[0] = d0;
-  for (int i = 0; i < nh; ++i) nd.d_[i + 1] = hidden[i];
-  nd.d_[nh + 1] = dout;
-  int off = 0, np = 0;
-  for (int l = 0; l < nd.L_; ++l) {
-    nd.kp_[l] = ddrl_roundup(nd.d_[l], 4);
-    nd.offw_[l] = off; off += nd.d_[l + 1] * nd.kp_[l];
-    nd.offb_[l] = off; off += ddrl_roundup(nd.d_[l + 1], 4);
-    np += nd.d_[l + 1] * nd.d_[l] + nd.d_[l + 1];
-  }
-  for (int i = 0; i <= nd.L_; ++i) nd.ld_[i] = ddrl_ldpad(nd.d_[i]);
-  nd.stride_ = ddrl_roundup(off, 64);
-  nd.np = np;
-  nd.hidden_act_ = hidden_act;
-  nd.out_act_ = out_act;
-}
-
-// flat reference order <-> padded device image of ONE agent
-static void pack_flat(const NetDesc &nd, const double *flat, float *img) {
-  size_t k = 0;
-  for (int l = 0; l < nd.L(); ++l) {
-    for (int n = 0; n < nd.d(l + 1); ++n)
-      for (int c = 0; c < nd.d(l); ++c) img[nd.offw(l) + n * nd.kp(l) + c] = (float)flat[k++];
-    for (int n = 0; n < nd.d(l + 1); ++n) img[nd.offb(l) + n] = (float)flat[k++];
-  }
-}
-static void unpack_flat(const NetDesc &nd, const float *img, double *flat) {
-  size_t k = 0;
-  for (int l = 0; l < nd.L(); ++l) {
-    for (int n = 0; n < nd.d(l + 1); ++n)
-      for (int c = 0; c < nd.d(l); ++c) flat[k++] = (double)img[nd.offw(l) + n * nd.kp(l) + c];
-    for (int n = 0; n < nd.d(l + 1); ++n) flat[k++] = (double)img[nd.offb(l) + n];
-  }
-}
-
-static int upload_flat(ddrl_pop *h, const NetDesc &nd, float *dst, const double *flat) {
-  std::vector<float> img((size_t)h->G * nd.stride(), 0.f);
-  for (int g = 0; g < h->G; ++g) pack_flat(nd, flat + (size_t)g * nd.np, img.data() + (size_t)g * nd.stride());
-  HIPCHK(hipMemcpyAsync(dst, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return DDRL_OK;
-}
-static int download_flat(ddrl_pop *h, const NetDesc &nd, const float *src, double *flat) {
-  std::vector<float> img((size_t)h->G * nd.stride());
-  HIPCHK(hipMemcpyAsync(img.data(), src, img.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  for (int g = 0; g < h->G; ++g) unpack_flat(nd, img.data() + (size_t)g * nd.stride(), flat + (size_t)g * nd.np);
-  return DDRL_OK;
-}
-
-template <class T>
-static int upload_vec(ddrl_pop *h, T *dst, const std::vector<T> &v) {
-  HIPCHK(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return DDRL_OK;
-}
-
-static int upload_mask(ddrl_pop *h, const uint8_t *mask, const uint8_t **dmask) {
-  *dmask = nullptr;
-  if (!mask) return DDRL_OK;
-  HIPCHK(hipMemcpyAsync(h->d_mask, mask, h->G, hipMemcpyHostToDevice, h->stream));
-  *dmask = h->d_mask;
-  return DDRL_OK;
-}
-
-static int set_device(ddrl_pop *h) {
-  HIPCHK(hipSetDevice(h->device));
-  return DDRL_OK;
-}
-
-static TrainNet *train_net(ddrl_pop *h, int net) { return (net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET) ? &h->net[0] : &h->net[1]; }
-static float *net_weights(ddrl_pop *h, int net) {
-  TrainNet *t = train_net(h, net);
-  return (net == DDRL_NET_ACTOR || net == DDRL_NET_CRITIC) ? t->st.w : t->st.wt;
-}
-
-static int refresh_ewc_coef(ddrl_pop *h, TrainNet &t) {
-  if (!t.ewc.enabled) return DDRL_OK;
-  std::vector<float> c(h->G);
-  for (int g = 0; g < h->G; ++g) {
-    double f = h->cfg.ewc_decay >= 0. ? t.ewc.decay_mult[g] : 1.;   // DODevMLP.hpp:691-693
-    c[g] = t.ewc.live[g] ? (float)(h->cfg.ewc * f) : 0.f;
-  }
-  return upload_vec(h, t.st.ewc_coef, c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -270,36 +103,6 @@ static int validate(const ddrl_ddpg_config *c) {
   if (c->nstep_return > 0) return ddrl_fail(DDRL_EINVAL, "nstep_return > 0 is not supported on the device path yet");
   if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
   if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
-  return DDRL_OK;
-}
-
-static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc) {
-  const size_t n = (size_t)h->G * t.nd.stride();
-  int rc;
-  if ((rc = dalloc(h, &t.st.w, n))) return rc;
-  if ((rc = dalloc(h, &t.st.m, n))) return rc;
-  if ((rc = dalloc(h, &t.st.v, n))) return rc;
-  if ((rc = dalloc(h, &t.st.wt, n))) return rc;
-  if ((rc = dalloc(h, &t.st.iter, h->G))) return rc;
-  if ((rc = dalloc(h, &t.d_lr, h->G))) return rc;
-  if ((rc = dalloc(h, &t.st.lr_t, h->G))) return rc;
-  if ((rc = dalloc(h, &t.d_decay, h->G))) return rc;
-  t.st.lr = t.d_lr;
-  t.st.decay = t.d_decay;
-  t.ewc.enabled = ewc;
-  if (ewc) {
-    if ((rc = dalloc(h, &t.st.fisher, n))) return rc;
-    if ((rc = dalloc(h, &t.st.fhat, n))) return rc;
-    if ((rc = dalloc(h, &t.st.wstar, n))) return rc;
-    if ((rc = dalloc(h, &t.st.best, n))) return rc;
-    if ((rc = dalloc(h, &t.st.fisher_nbr, h->G))) return rc;
-    if ((rc = dalloc(h, &t.st.ewc_coef, h->G))) return rc;
-    t.ewc.best_score.assign(h->G, std::numeric_limits<double>::lowest());
-    t.ewc.decay_mult.assign(h->G, 1.0);
-    t.ewc.last_update_best.assign(h->G, 0);
-    t.ewc.best_valid.assign(h->G, 0);
-    t.ewc.live.assign(h->G, 0);
-  }
   return DDRL_OK;
 }
 
@@ -415,6 +218,7 @@ extern "C" int ddrl_pop_destroy(ddrl_pop_t *h) {
   for (void *p : h->allocs) (void)hipFree(p);
   for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->nfac) ddrl_nfac_host_free(h->nfac);
   delete h;
   return DDRL_OK;
 }
@@ -437,6 +241,7 @@ extern "C" int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *
     return upload_vec(h, k == "alpha_a" ? h->net[0].d_lr : h->net[1].d_lr, f);
   }
   if (k == "tau_soft_update") {
+    DDPG_ONLY(h);
     std::vector<float> om(G);
     // MLP.hpp:449-450: axpby(tau, from, (1.f - tau), to) -- (1.f - tau) evaluated in double
     for (int g = 0; g < G; ++g) { f[g] = (float)v[g]; om[g] = (float)(1.f - v[g]); }
@@ -444,24 +249,24 @@ extern "C" int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *
     return upload_vec(h, h->d_omtau, om);
   }
   if (k == "gamma") { for (int g = 0; g < G; ++g) f[g] = (float)v[g]; return upload_vec(h, h->d_gamma, f); }
-  if (k == "decay_v") { for (int g = 0; g < G; ++g) f[g] = (float)v[g]; return upload_vec(h, h->net[1].d_decay, f); }
+  if (k == "decay_v") { DDPG_ONLY(h); for (int g = 0; g < G; ++g) f[g] = (float)v[g]; return upload_vec(h, h->net[1].d_decay, f); }
   return ddrl_fail(DDRL_EINVAL, "unknown hyper-parameter '%s'", key);
 }
 
 extern "C" int ddrl_pop_num_params(ddrl_pop_t *h, int net) {
-  if (!h || net < 0 || net > 3) return ddrl_fail(DDRL_EINVAL, "bad handle/net");
+  if (!h || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad handle/net");
   return train_net(h, net)->nd.np;
 }
 
 extern "C" int ddrl_pop_set_weights(ddrl_pop_t *h, int net, const double *flat) {
-  if (!h || !flat || net < 0 || net > 3) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  if (!h || !flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   int rc = set_device(h);
   if (rc) return rc;
   return upload_flat(h, train_net(h, net)->nd, net_weights(h, net), flat);
 }
 
 extern "C" int ddrl_pop_get_weights(ddrl_pop_t *h, int net, double *flat) {
-  if (!h || !flat || net < 0 || net > 3) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  if (!h || !flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   int rc = set_device(h);
   if (rc) return rc;
   return download_flat(h, train_net(h, net)->nd, net_weights(h, net), flat);
@@ -497,6 +302,7 @@ extern "C" int ddrl_pop_set_adam(ddrl_pop_t *h, int net, const double *m, const 
 
 extern "C" int ddrl_pop_seed_replay(ddrl_pop_t *h, const uint32_t *seeds) {
   if (!h || !seeds) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  DDPG_ONLY(h);
   int rc = set_device(h);
   if (rc) return rc;
   uint32_t *d_seeds = (uint32_t *)h->d_idx;   // G words of scratch (d_idx holds G*B >= G ints)
@@ -509,6 +315,7 @@ extern "C" int ddrl_pop_seed_replay(ddrl_pop_t *h, const uint32_t *seeds) {
 extern "C" int ddrl_pop_replay_append(ddrl_pop_t *h, const float *s, const float *a, const float *r,
                                       const float *s2, const uint8_t *goal, const uint8_t *mask) {
   if (!h || !s || !a || !r || !s2 || !goal) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  DDPG_ONLY(h);
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
@@ -533,6 +340,7 @@ extern "C" int ddrl_pop_replay_append(ddrl_pop_t *h, const float *s, const float
 extern "C" int ddrl_pop_replay_load(ddrl_pop_t *h, int agent, int n, const float *rows) {
   if (!h || !rows || agent < 0 || agent >= h->G || n < 0 || n > h->cfg.replay_memory)
     return ddrl_fail(DDRL_EINVAL, "bad argument");
+  DDPG_ONLY(h);
   int rc = set_device(h);
   if (rc) return rc;
   const int S = h->cfg.nb_sensors, A = h->cfg.nb_motors, rl = 2 * S + A + 2;
@@ -550,6 +358,7 @@ extern "C" int ddrl_pop_replay_load(ddrl_pop_t *h, int agent, int n, const float
 
 extern "C" int ddrl_pop_replay_len(ddrl_pop_t *h, int32_t *len) {
   if (!h || !len) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  DDPG_ONLY(h);
   int rc = set_device(h);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(len, h->d_len, h->G * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -579,6 +388,7 @@ extern "C" int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions
 
 extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  DDPG_ONLY(h);
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, B = h->cfg.mini_batch_size;
@@ -619,6 +429,7 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
 
 extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *qt, float *dact) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  DDPG_ONLY(h);
   int rc = set_device(h);
   if (rc) return rc;
   const size_t G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;

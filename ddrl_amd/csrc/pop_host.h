@@ -1,0 +1,213 @@
+// pop_host.h -- host-side handle of libddrl_pop.so and the helpers shared by pop.hip (DDPG) and
+// nfac.hip (NFAC(lambda)-V).  Not part of the C ABI.
+#pragma once
+#include "../../include/ddrl_pop.h"
+#include "pop_internal.h"
+#include "host_util.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <vector>
+
+struct NfacHost;   // nfac.hip
+void ddrl_nfac_host_free(NfacHost *n);
+
+// ---------------------------------------------------------------------------------------------
+// per-net host bookkeeping of the EWC life-cycle (DODevMLP.hpp:803-822)
+struct EwcHost {
+  bool enabled = false;
+  std::vector<double> best_score, decay_mult;
+  std::vector<int> last_update_best;
+  std::vector<uint8_t> best_valid, live;
+};
+
+struct TrainNet {
+  NetDesc nd;
+  NetState st;           // device pointers
+  EwcHost ewc;
+  float *d_lr = nullptr, *d_decay = nullptr;
+};
+
+struct ddrl_pop {
+  int algo = 0;                    // 0 DDPG, 1 NFAC
+  NfacHost *nfac = nullptr;        // algo == 1
+  ddrl_ddpg_config cfg;            // NFAC handles fill the fields the shared entry points read
+  int G = 0, device = 0;
+  hipStream_t stream = nullptr;
+  TrainNet net[2];                 // 0 actor, 1 critic  (targets hang off st.wt)
+  // replay
+  int rowlen = 0;
+  float *d_rep = nullptr;
+  int *d_len = nullptr, *d_head = nullptr;
+  std::vector<int> h_len, h_head;
+  uint32_t *d_mt = nullptr;
+  int *d_mtpos = nullptr;
+  int *d_idx = nullptr;
+  // hyper
+  float *d_tau = nullptr, *d_omtau = nullptr, *d_gamma = nullptr;
+  // diagnostics
+  float *d_loss = nullptr, *d_qt = nullptr, *d_dact = nullptr;
+  long long *d_stamps = nullptr;
+  // staging
+  float *d_s = nullptr, *d_a = nullptr, *d_r = nullptr, *d_s2 = nullptr, *d_act = nullptr, *d_cost = nullptr;
+  uint8_t *d_goal = nullptr, *d_mask = nullptr, *d_flag = nullptr;
+  std::vector<void *> allocs;
+  DdpgParams P;
+  // measurement
+  bool profiling = false;
+  int force_generic = 0;
+  double beta1 = 0., beta2 = 0.999;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+};
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return ddrl_fail(DDRL_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+static int dalloc(ddrl_pop *h, T **p, size_t n, bool zero = true) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) return ddrl_fail(DDRL_ENOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+  h->allocs.push_back(q);
+  if (zero) {
+    e = hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream);
+    if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "hipMemset: %s", hipGetErrorString(e));
+  }
+  *p = (T *)q;
+  return DDRL_OK;
+}
+
+static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout, int hidden_act, int out_act) {
+  memset(&nd, 0, sizeof(nd));
+  nd.L_ = nh + 1;
+  nd.d_[0] = d0;
+  for (int i = 0; i < nh; ++i) nd.d_[i + 1] = hidden[i];
+  nd.d_[nh + 1] = dout;
+  int off = 0, np = 0;
+  for (int l = 0; l < nd.L_; ++l) {
+    nd.kp_[l] = ddrl_roundup(nd.d_[l], 4);
+    nd.offw_[l] = off; off += nd.d_[l + 1] * nd.kp_[l];
+    nd.offb_[l] = off; off += ddrl_roundup(nd.d_[l + 1], 4);
+    np += nd.d_[l + 1] * nd.d_[l] + nd.d_[l + 1];
+  }
+  for (int i = 0; i <= nd.L_; ++i) nd.ld_[i] = ddrl_ldpad(nd.d_[i]);
+  nd.stride_ = ddrl_roundup(off, 64);
+  nd.np = np;
+  nd.hidden_act_ = hidden_act;
+  nd.out_act_ = out_act;
+}
+
+// flat reference order <-> padded device image of ONE agent
+static void pack_flat(const NetDesc &nd, const double *flat, float *img) {
+  size_t k = 0;
+  for (int l = 0; l < nd.L(); ++l) {
+    for (int n = 0; n < nd.d(l + 1); ++n)
+      for (int c = 0; c < nd.d(l); ++c) img[nd.offw(l) + n * nd.kp(l) + c] = (float)flat[k++];
+    for (int n = 0; n < nd.d(l + 1); ++n) img[nd.offb(l) + n] = (float)flat[k++];
+  }
+}
+static void unpack_flat(const NetDesc &nd, const float *img, double *flat) {
+  size_t k = 0;
+  for (int l = 0; l < nd.L(); ++l) {
+    for (int n = 0; n < nd.d(l + 1); ++n)
+      for (int c = 0; c < nd.d(l); ++c) flat[k++] = (double)img[nd.offw(l) + n * nd.kp(l) + c];
+    for (int n = 0; n < nd.d(l + 1); ++n) flat[k++] = (double)img[nd.offb(l) + n];
+  }
+}
+
+static int upload_flat(ddrl_pop *h, const NetDesc &nd, float *dst, const double *flat) {
+  std::vector<float> img((size_t)h->G * nd.stride(), 0.f);
+  for (int g = 0; g < h->G; ++g) pack_flat(nd, flat + (size_t)g * nd.np, img.data() + (size_t)g * nd.stride());
+  HIPCHK(hipMemcpyAsync(dst, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+static int download_flat(ddrl_pop *h, const NetDesc &nd, const float *src, double *flat) {
+  std::vector<float> img((size_t)h->G * nd.stride());
+  HIPCHK(hipMemcpyAsync(img.data(), src, img.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int g = 0; g < h->G; ++g) unpack_flat(nd, img.data() + (size_t)g * nd.stride(), flat + (size_t)g * nd.np);
+  return DDRL_OK;
+}
+
+template <class T>
+static int upload_vec(ddrl_pop *h, T *dst, const std::vector<T> &v) {
+  HIPCHK(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+static int upload_mask(ddrl_pop *h, const uint8_t *mask, const uint8_t **dmask) {
+  *dmask = nullptr;
+  if (!mask) return DDRL_OK;
+  HIPCHK(hipMemcpyAsync(h->d_mask, mask, h->G, hipMemcpyHostToDevice, h->stream));
+  *dmask = h->d_mask;
+  return DDRL_OK;
+}
+
+static int set_device(ddrl_pop *h) {
+  HIPCHK(hipSetDevice(h->device));
+  return DDRL_OK;
+}
+
+static TrainNet *train_net(ddrl_pop *h, int net) { return (net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET) ? &h->net[0] : &h->net[1]; }
+static float *net_weights(ddrl_pop *h, int net) {
+  TrainNet *t = train_net(h, net);
+  return (net == DDRL_NET_ACTOR || net == DDRL_NET_CRITIC) ? t->st.w : t->st.wt;
+}
+
+static int refresh_ewc_coef(ddrl_pop *h, TrainNet &t) {
+  if (!t.ewc.enabled) return DDRL_OK;
+  std::vector<float> c(h->G);
+  for (int g = 0; g < h->G; ++g) {
+    double f = h->cfg.ewc_decay >= 0. ? t.ewc.decay_mult[g] : 1.;   // DODevMLP.hpp:691-693
+    c[g] = t.ewc.live[g] ? (float)(h->cfg.ewc * f) : 0.f;
+  }
+  return upload_vec(h, t.st.ewc_coef, c);
+}
+
+
+static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc, bool target = true) {
+  const size_t n = (size_t)h->G * t.nd.stride();
+  int rc;
+  if ((rc = dalloc(h, &t.st.w, n))) return rc;
+  if ((rc = dalloc(h, &t.st.m, n))) return rc;
+  if ((rc = dalloc(h, &t.st.v, n))) return rc;
+  if (target && (rc = dalloc(h, &t.st.wt, n))) return rc;
+  if ((rc = dalloc(h, &t.st.iter, h->G))) return rc;
+  if ((rc = dalloc(h, &t.d_lr, h->G))) return rc;
+  if ((rc = dalloc(h, &t.st.lr_t, h->G))) return rc;
+  if ((rc = dalloc(h, &t.d_decay, h->G))) return rc;
+  t.st.lr = t.d_lr;
+  t.st.decay = t.d_decay;
+  t.ewc.enabled = ewc;
+  if (ewc) {
+    if ((rc = dalloc(h, &t.st.fisher, n))) return rc;
+    if ((rc = dalloc(h, &t.st.fhat, n))) return rc;
+    if ((rc = dalloc(h, &t.st.wstar, n))) return rc;
+    if ((rc = dalloc(h, &t.st.best, n))) return rc;
+    if ((rc = dalloc(h, &t.st.fisher_nbr, h->G))) return rc;
+    if ((rc = dalloc(h, &t.st.ewc_coef, h->G))) return rc;
+    t.ewc.best_score.assign(h->G, std::numeric_limits<double>::lowest());
+    t.ewc.decay_mult.assign(h->G, 1.0);
+    t.ewc.last_update_best.assign(h->G, 0);
+    t.ewc.best_valid.assign(h->G, 0);
+    t.ewc.live.assign(h->G, 0);
+  }
+  return DDRL_OK;
+}
+
+
+// NFAC populations have no target nets (OfflineCaclaAg.hpp:186-196)
+static bool bad_net(ddrl_pop *h, int net) { return net < 0 || net > 3 || (h->algo == 1 && net > DDRL_NET_CRITIC); }
+#define DDPG_ONLY(h) do { if ((h)->algo != 0) return ddrl_fail(DDRL_ESTATE, "%s: DDPG populations only", __func__); } while (0)
+

@@ -109,3 +109,27 @@ struct DdpgParams {
   float *dact_out;          // [G x B x A] or null
   long long *stamps;        // [G x 16] s_memtime at phase boundaries (diagnostic), or null
 };
+
+// NFAC(lambda)-V kernels (kernels_nfac.hip)
+struct NfacParams {
+  NetDesc a, v;
+  NetState sa, sv;
+  int G, S, A, maxT, rowlen, maxchunks;
+  int ldh;                        // LDS row stride reserved for hidden activations
+  int inverting, update_delta_neg, gae;
+  float lambda;
+  float beta1, beta2, omb1, omb2, eps, fisher_beta;
+  double dbeta1, dbeta2;
+  const float *traj;              // [G x maxT x rowlen] rows: s, pure_a, a, s2, r, goal
+  const int *len;                 // [G]
+  const uint8_t *endflag;         // [G x maxT] row is the last transition of its episode
+  const float *gamma;             // [G]
+  const uint8_t *mask;            // [G] or null
+  float *V, *nextV, *tgt, *deltas;   // [G x maxT]
+  uint8_t *rowmode;               // [G x maxT] 0: no gradient, 1: target = a, 2: target = pure_a
+  int *n_pos;                     // [G]
+  float *gpart_a, *gpart_v;       // [G x maxchunks x stride] per net; pads are zero and stay zero
+  float *loss_part;               // [G x maxchunks]
+  float *loss_out;                // [G]
+};
+

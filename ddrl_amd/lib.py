@@ -35,6 +35,23 @@ class DdpgConfigC(C.Structure):
     ]
 
 
+class NfacConfigC(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int), ("nb_sensors", C.c_int), ("nb_motors", C.c_int),
+        ("n_hidden_a", C.c_int), ("hidden_unit_a", C.c_int * DDRL_MAX_HIDDEN),
+        ("n_hidden_v", C.c_int), ("hidden_unit_v", C.c_int * DDRL_MAX_HIDDEN),
+        ("update_delta_neg", C.c_int), ("update_critic_first", C.c_int),
+        ("number_fitted_iteration", C.c_int), ("stoch_iter_actor", C.c_int), ("stoch_iter_critic", C.c_int),
+        ("batch_norm_actor", C.c_int), ("batch_norm_critic", C.c_int),
+        ("actor_output_layer_type", C.c_int), ("hidden_layer_type", C.c_int), ("momentum", C.c_int),
+        ("gae", C.c_int), ("inverting_gradient", C.c_int), ("max_trajectory", C.c_int),
+        ("gamma", C.c_double), ("lambda_", C.c_double), ("alpha_a", C.c_double), ("alpha_v", C.c_double),
+        ("ewc", C.c_double), ("ewc_decay", C.c_double), ("ewc_fisher_beta", C.c_double),
+        ("ewc_best_param_method", C.c_int), ("ewc_for_critic", C.c_int),
+        ("device", C.c_int),
+    ]
+
+
 # every symbol include/ddrl_pop.h declares: (name, restype, argtypes)
 _vp, _i, _cp = C.c_void_p, C.c_int, C.c_char_p
 SYMBOLS = [
@@ -68,6 +85,15 @@ SYMBOLS = [
     ("ddrl_pop_profile_read", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     ("ddrl_pop_debug_stamps", _i, [_vp, _i, _vp]),
     ("ddrl_pop_set_option", _i, [_vp, _cp, _i]),
+    ("ddrl_nfac_config_default", _i, [C.POINTER(NfacConfigC)]),
+    ("ddrl_nfac_config_from_ini", _i, [_cp, C.POINTER(NfacConfigC)]),
+    ("ddrl_nfac_create", _i, [C.POINTER(NfacConfigC), C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_nfac_traj_append", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_nfac_traj_load", _i, [_vp, _i, _i, _vp, _i, _vp]),
+    ("ddrl_nfac_episode_end", _i, [_vp, _vp]),
+    ("ddrl_nfac_traj_len", _i, [_vp, _vp]),
+    ("ddrl_nfac_update", _i, [_vp, _vp]),
+    ("ddrl_nfac_last", _i, [_vp, _vp, _vp, _vp]),
     ("ddrl_cmaes_create", _i, [_i, _vp, _vp, C.c_long, _i, _i, C.POINTER(_vp)]),
     ("ddrl_cmaes_destroy", _i, [_vp]),
     ("ddrl_cmaes_sample", _i, [_vp]),

@@ -53,16 +53,8 @@ class DdpgConfig:
         return getattr(self.c, k)
 
 
-class DdpgPopulation:
-    """G independent DDPG agents on one GPU (DeepQNAg<MLP> x G)."""
-
-    def __init__(self, cfg, init_seed=0):
-        self.L = _l.load()
-        self.cfg = cfg
-        h = C.c_void_p()
-        _l.check(self.L.ddrl_ddpg_create(C.byref(cfg.c), init_seed, C.byref(h)))
-        self.h = h
-        self.G, self.S, self.A, self.B = cfg.c.n_agents, cfg.c.nb_sensors, cfg.c.nb_motors, cfg.c.mini_batch_size
+class Population:
+    """What DDPG and NFAC populations share: weights, Adam state, inference, the EWC life-cycle."""
 
     def close(self):
         if getattr(self, "h", None):
@@ -105,47 +97,12 @@ class DdpgPopulation:
         it = np.ascontiguousarray(it, np.int32)
         _l.check(self.L.ddrl_pop_set_adam(self.h, net, _p(m), _p(v), _p(it)))
 
-    def seed_replay(self, seeds):
-        s = np.ascontiguousarray(seeds, np.uint32).reshape(self.G)
-        _l.check(self.L.ddrl_pop_seed_replay(self.h, _p(s)))
-
-    def replay_append(self, s, a, r, s2, goal, mask=None):
-        f = lambda x, n: np.ascontiguousarray(x, np.float32).reshape(self.G, n)
-        s, a, s2 = f(s, self.S), f(a, self.A), f(s2, self.S)
-        r = np.ascontiguousarray(r, np.float32).reshape(self.G)
-        goal = np.ascontiguousarray(goal, np.uint8).reshape(self.G)
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
-        _l.check(self.L.ddrl_pop_replay_append(self.h, _p(s), _p(a), _p(r), _p(s2), _p(goal), _p(m)))
-
-    def replay_load(self, agent, rows):
-        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 2 * self.S + self.A + 2)
-        _l.check(self.L.ddrl_pop_replay_load(self.h, agent, rows.shape[0], _p(rows)))
-
-    def replay_len(self):
-        out = np.empty(self.G, np.int32)
-        _l.check(self.L.ddrl_pop_replay_len(self.h, _p(out)))
-        return out
-
     # ann_testing->computeOut(sensors) for every agent
     def infer(self, states):
         s = np.ascontiguousarray(states, np.float32).reshape(self.G, self.S)
         out = np.empty((self.G, self.A), np.float32)
         _l.check(self.L.ddrl_pop_infer(self.h, _p(s), _p(out)))
         return out
-
-    # one pass of end_episode's fupd loop body for every (masked) agent
-    def update(self, idx=None, mask=None):
-        i = None if idx is None else np.ascontiguousarray(idx, np.int32).reshape(self.G, self.B)
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
-        _l.check(self.L.ddrl_pop_ddpg_update(self.h, _p(i), _p(m)))
-
-    def last(self):
-        idx = np.empty((self.G, self.B), np.int32)
-        loss = np.empty(self.G, np.float32)
-        qt = np.empty((self.G, self.B), np.float32)
-        da = np.empty((self.G, self.B, self.A), np.float32)
-        _l.check(self.L.ddrl_pop_ddpg_last(self.h, _p(idx), _p(loss), _p(qt), _p(da)))
-        return dict(idx=idx, loss=loss, q_targets=qt, dact=da)
 
     def update_best_param(self, score, mask=None):
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(score, np.float64), (self.G,)))
@@ -181,5 +138,140 @@ class DdpgPopulation:
         _l.check(self.L.ddrl_pop_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+
+class DdpgPopulation(Population):
+    """G independent DDPG agents on one GPU (DeepQNAg<MLP> x G)."""
+
+    def __init__(self, cfg, init_seed=0):
+        self.L = _l.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_ddpg_create(C.byref(cfg.c), init_seed, C.byref(h)))
+        self.h = h
+        self.G, self.S, self.A, self.B = cfg.c.n_agents, cfg.c.nb_sensors, cfg.c.nb_motors, cfg.c.mini_batch_size
+
+    def seed_replay(self, seeds):
+        s = np.ascontiguousarray(seeds, np.uint32).reshape(self.G)
+        _l.check(self.L.ddrl_pop_seed_replay(self.h, _p(s)))
+
+    def replay_append(self, s, a, r, s2, goal, mask=None):
+        f = lambda x, n: np.ascontiguousarray(x, np.float32).reshape(self.G, n)
+        s, a, s2 = f(s, self.S), f(a, self.A), f(s2, self.S)
+        r = np.ascontiguousarray(r, np.float32).reshape(self.G)
+        goal = np.ascontiguousarray(goal, np.uint8).reshape(self.G)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_replay_append(self.h, _p(s), _p(a), _p(r), _p(s2), _p(goal), _p(m)))
+
+    def replay_load(self, agent, rows):
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 2 * self.S + self.A + 2)
+        _l.check(self.L.ddrl_pop_replay_load(self.h, agent, rows.shape[0], _p(rows)))
+
+    def replay_len(self):
+        out = np.empty(self.G, np.int32)
+        _l.check(self.L.ddrl_pop_replay_len(self.h, _p(out)))
+        return out
+
+    # one pass of end_episode's fupd loop body for every (masked) agent
+    def update(self, idx=None, mask=None):
+        i = None if idx is None else np.ascontiguousarray(idx, np.int32).reshape(self.G, self.B)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_ddpg_update(self.h, _p(i), _p(m)))
+
+    def last(self):
+        idx = np.empty((self.G, self.B), np.int32)
+        loss = np.empty(self.G, np.float32)
+        qt = np.empty((self.G, self.B), np.float32)
+        da = np.empty((self.G, self.B, self.A), np.float32)
+        _l.check(self.L.ddrl_pop_ddpg_last(self.h, _p(idx), _p(loss), _p(qt), _p(da)))
+        return dict(idx=idx, loss=loss, q_targets=qt, dact=da)
+
     def set_option(self, key, value):
         _l.check(self.L.ddrl_pop_set_option(self.h, key.encode(), int(value)))
+
+
+class NfacConfig:
+    """The [agent]/[devnn] keys of OfflineCaclaAg::_unique_invoke (OfflineCaclaAg.hpp:124-179)."""
+
+    def __init__(self, **kw):
+        self.c = _l.NfacConfigC()
+        _l.check(_l.load().ddrl_nfac_config_default(C.byref(self.c)))
+        for k, v in kw.items():
+            self.set(k, v)
+
+    @classmethod
+    def from_ini(cls, path, n_agents=1, nb_sensors=0, nb_motors=0, max_trajectory=0):
+        o = cls()
+        o.c.n_agents, o.c.nb_sensors, o.c.nb_motors, o.c.max_trajectory = n_agents, nb_sensors, nb_motors, max_trajectory
+        _l.check(_l.load().ddrl_nfac_config_from_ini(path.encode(), C.byref(o.c)))
+        return o
+
+    def set(self, k, v):
+        if k == "lambda":
+            k = "lambda_"
+        if k in ("hidden_unit_a", "hidden_unit_v"):
+            v = list(v)
+            if len(v) > _l.DDRL_MAX_HIDDEN:
+                raise ValueError("at most %d hidden layers" % _l.DDRL_MAX_HIDDEN)
+            arr = getattr(self.c, k)
+            for i, x in enumerate(v):
+                arr[i] = int(x)
+            setattr(self.c, "n_hidden_" + k[-1], len(v))
+        elif hasattr(self.c, k):
+            setattr(self.c, k, v)
+        else:
+            raise KeyError(k)
+
+    def get(self, k):
+        if k == "lambda":
+            k = "lambda_"
+        if k in ("hidden_unit_a", "hidden_unit_v"):
+            return list(getattr(self.c, k))[: getattr(self.c, "n_hidden_" + k[-1])]
+        return getattr(self.c, k)
+
+
+class NfacPopulation(Population):
+    """G independent NFAC(lambda)-V agents on one GPU (OfflineCaclaAg<MLP> x G); nets: NET_ACTOR = ann,
+    NET_CRITIC = vnn."""
+
+    def __init__(self, cfg, init_seed=0):
+        self.L = _l.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_nfac_create(C.byref(cfg.c), init_seed, C.byref(h)))
+        self.h = h
+        self.G, self.S, self.A, self.maxT = cfg.c.n_agents, cfg.c.nb_sensors, cfg.c.nb_motors, cfg.c.max_trajectory
+
+    # trajectory.push_back({s, pure_a, a, next_s, r, goal}) for every (masked) agent
+    def traj_append(self, s, pure_a, a, s2, r, goal, mask=None):
+        f = lambda x, n: np.ascontiguousarray(x, np.float32).reshape(self.G, n)
+        s, pure_a, a, s2 = f(s, self.S), f(pure_a, self.A), f(a, self.A), f(s2, self.S)
+        r = np.ascontiguousarray(r, np.float32).reshape(self.G)
+        goal = np.ascontiguousarray(goal, np.uint8).reshape(self.G)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_nfac_traj_append(self.h, _p(s), _p(pure_a), _p(a), _p(s2), _p(r), _p(goal), _p(m)))
+
+    def traj_load(self, agent, rows, ends):
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 2 * self.S + 2 * self.A + 2)
+        ends = np.ascontiguousarray(ends, np.int32)
+        _l.check(self.L.ddrl_nfac_traj_load(self.h, agent, rows.shape[0], _p(rows), ends.size, _p(ends)))
+
+    def episode_end(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_nfac_episode_end(self.h, _p(m)))
+
+    def traj_len(self):
+        out = np.empty(self.G, np.int32)
+        _l.check(self.L.ddrl_nfac_traj_len(self.h, _p(out)))
+        return out
+
+    # the learning branch of OfflineCaclaAg::end_episode for every (masked) agent
+    def update(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_nfac_update(self.h, _p(m)))
+
+    def last(self):
+        deltas = np.empty((self.G, self.maxT), np.float32)
+        n = np.empty(self.G, np.int32)
+        loss = np.empty(self.G, np.float32)
+        _l.check(self.L.ddrl_nfac_last(self.h, _p(deltas), _p(n), _p(loss)))
+        return dict(deltas=deltas, n_pos=n, critic_loss=loss)

@@ -137,6 +137,55 @@ int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost /* [G] */);
 int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat, double *wstar,
                      double *fisher_nbr /* [G] */, double *decay_mult /* [G] */);
 
+/* ------------------------------------------------------------------------------------------------
+ * NFAC(lambda)-V (agent/cacla/include/OfflineCaclaAg.hpp): population of G independent agents,
+ * each with an actor and a V critic (no target nets).  An NFAC handle is a ddrl_pop_t: the weight /
+ * Adam / EWC / inference / set_hyper("alpha_a","alpha_v","gamma") entry points above apply to it with
+ * net = DDRL_NET_ACTOR or DDRL_NET_CRITIC (= vnn); the replay and ddpg entry points do not.
+ * ---------------------------------------------------------------------------------------------- */
+/* the [agent] keys OfflineCaclaAg::_unique_invoke reads (OfflineCaclaAg.hpp:124-179) + [devnn] */
+typedef struct {
+  int    n_agents, nb_sensors, nb_motors;
+  int    n_hidden_a; int hidden_unit_a[DDRL_MAX_HIDDEN];
+  int    n_hidden_v; int hidden_unit_v[DDRL_MAX_HIDDEN];
+  int    update_delta_neg, update_critic_first;
+  int    number_fitted_iteration, stoch_iter_actor, stoch_iter_critic;
+  int    batch_norm_actor, batch_norm_critic;      /* must be 0 */
+  int    actor_output_layer_type, hidden_layer_type, momentum;
+  int    gae, inverting_gradient;
+  int    max_trajectory;           /* capacity (transitions) of each agent's trajectory buffer */
+  double gamma, lambda, alpha_a, alpha_v;
+  double ewc, ewc_decay, ewc_fisher_beta;
+  int    ewc_best_param_method, ewc_for_critic;
+  int    device;
+} ddrl_nfac_config;
+
+int ddrl_nfac_config_default(ddrl_nfac_config *cfg);
+int ddrl_nfac_config_from_ini(const char *path, ddrl_nfac_config *cfg);
+/* OfflineCaclaAg ctor + _unique_invoke (OfflineCaclaAg.hpp:59-62,122-209; C flavour
+ * agent/cacla/src/pybinding/nfac.cpp:17-50) */
+int ddrl_nfac_create(const ddrl_nfac_config *cfg, uint64_t init_seed, ddrl_pop_t **out);
+/* trajectory.push_back({s, pure_a, a, next_s, r, goal}) (OfflineCaclaAg.hpp:84-85), one transition
+ * per agent with mask[g] != 0 */
+int ddrl_nfac_traj_append(ddrl_pop_t *h, const float *s, const float *pure_a, const float *a,
+                          const float *s2, const float *r, const uint8_t *goal, const uint8_t *mask);
+/* bulk form: replaces agent's trajectory by n rows [n x (2S+2A+2)] = s, pure_a, a, s2, r, goal and its
+ * trajectory_end_points by ends[n_ends] */
+int ddrl_nfac_traj_load(ddrl_pop_t *h, int agent, int n, const float *rows, int n_ends, const int32_t *ends);
+/* trajectory_end_points.push_back(trajectory.size()) (OfflineCaclaAg.hpp:419) */
+int ddrl_nfac_episode_end(ddrl_pop_t *h, const uint8_t *mask);
+int ddrl_nfac_traj_len(ddrl_pop_t *h, int32_t *len /* [G] */);
+/* the learning branch of OfflineCaclaAg::end_episode after the update_each_episode gate
+ * (OfflineCaclaAg.hpp:423-594) for every agent with mask[g] != 0: critic fits (update_critic,
+ * :242-401: TD(0) or lambda-return targets, number_fitted_iteration x stoch_iter_critic full-batch
+ * Adam steps), advantages (optional GAE), CACLA target selection, stoch_iter_actor full-batch actor
+ * steps, then trajectory.clear() and ewc_decay_update().  The batch is the whole trajectory
+ * (increase_batchsize, MLP.hpp:403-435): any length up to max_trajectory. */
+int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask);
+/* diagnostics of the last update: advantages [G x max_trajectory] (row-padded), n = number of
+ * positively advantaged transitions [G], last critic loss [G] */
+int ddrl_nfac_last(ddrl_pop_t *h, float *deltas, int32_t *n_pos, float *critic_loss);
+
 
 /* ------------------------------------------------------------------------------------------------
  * CMA-ES policy search (agent/cmaes): the vendored c-cmaes (agent/cmaes/src/cmaes.c) as driven by
