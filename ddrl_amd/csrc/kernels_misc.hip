@@ -150,10 +150,10 @@ infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restr
     for (int n = lane; n < ddrl_roundup(N, 4); n += 64) {
       float y = 0.f;
       if (n < N) {
-        const float *row = wa + nd.offw(l) + (size_t)n * kp;
+        const float *wl = wa + nd.offw(l);
         float s = 0.f;
         for (int k = 0; k < kp; k += 4) {
-          const f32x4 wv = *(const f32x4 *)(row + k);
+          const f32x4 wv = *(const f32x4 *)(wl + ddrl_widx(n, k, kp));
           const f32x4 xv = *(const f32x4 *)(&buf[cur][k]);
           s = fmaf(wv[0], xv[0], s); s = fmaf(wv[1], xv[1], s);
           s = fmaf(wv[2], xv[2], s); s = fmaf(wv[3], xv[3], s);

@@ -50,17 +50,18 @@ struct BFrag { f32x4 v[DDRL_MAXKC]; };
 
 __device__ __forceinline__ void load_bfrag(const float *__restrict__ W, int kp, int N, int nt, int lane, BFrag &b) {
   const int g = lane >> 4, c = lane & 15;
-  const int n = nt * 16 + c;
-  const float *wrow = W + (size_t)(n < N ? n : N - 1) * kp;
-  // no divergent branch around a load: the address is clamped into the row and the value masked
+  // tile-major storage: block (nt, kc) is contiguous and lane (c, g)'s float4 sits at c*kw + 4g, so
+  // a full block is one 1-KiB wave load.  Pad rows (n >= N) exist in memory and hold zeros.
+  // No divergent branch around a load: the address is clamped into the block and the value masked
   // afterwards, so the compiler can count the outstanding loads exactly (a load inside a lane-
   // dependent branch makes it fall back to s_waitcnt vmcnt(0) at the join)
 #pragma unroll
   for (int kc = 0; kc < DDRL_MAXKC; ++kc) {
     if (kc * 16 < kp) {                       // uniform (folds for compile-time shapes)
-      const int k = kc * 16 + 4 * g;
-      const f32x4 v = *(const f32x4 *)(wrow + (k < kp ? k : kp - 4));
-      b.v[kc] = (kc * 16 + 16 <= kp || k < kp) ? v : zero4();
+      const int kw = ddrl_tile_kw(kc, kp);
+      const float *blk = W + ddrl_tile_base(nt, kc, kp) + c * kw;
+      const f32x4 v = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
+      b.v[kc] = (kw == 16 || 4 * g < kw) ? v : zero4();
     }
   }
 }
@@ -148,18 +149,16 @@ __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, i
     for (int mt = 0; mt < 4; ++mt) acc[i][mt] = zero4();
     const int kt = kt0 + wave + DDRL_NWAVES * i;
     if (kt < kt1) {
-      const int col = kt * 16 + c;
-      const int colc = col < kp ? col : kp - 1;        // clamp: columns >= kp are discarded
+      const int kw = ddrl_tile_kw(kt, kp);
+      const int cc = c < kw ? c : kw - 1;              // clamp: columns >= kp are discarded
       float b[DDRL_MAXKC][4];
 #pragma unroll
       for (int nc = 0; nc < DDRL_MAXKC; ++nc)
         if (nc * 16 < N) {
+          // block (nc, kt) of the tile-major weights; pad rows (nn >= N) are stored and hold zeros
+          const float *blk = W + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + cc;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int nn = nc * 16 + 4 * g + j;
-            const float v = W[(size_t)(nn < N ? nn : N - 1) * kp + colc];     // clamped, then masked
-            b[nc][j] = (nc * 16 + 16 <= N || nn < N) ? v : 0.f;
-          }
+          for (int j = 0; j < 4; ++j) b[nc][j] = blk[j * kw];
         }
 #pragma unroll
       for (int nc = 0; nc < DDRL_MAXKC; ++nc) {
@@ -273,7 +272,7 @@ __device__ __forceinline__ int dw_elem(int p, int total, int KT, int N, int kp, 
   const int nt = pc / KT, kt = pc - nt * KT;
   const int n = nt * 16 + c, k = kt * 16 + 4 * g;
   ok = p < total && n < N && k < kp;
-  return ok ? offw + n * kp + k : offw;
+  return ok ? offw + ddrl_tile_base(nt, kt, kp) + c * ddrl_tile_kw(kt, kp) + 4 * g : offw;
 }
 
 // one 16 x 16 tile of dW^T = X^T dY (64-deep), result lane layout: see bwd_dw_opt

@@ -95,7 +95,7 @@ static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout,
   int off = 0, np = 0;
   for (int l = 0; l < nd.L_; ++l) {
     nd.kp_[l] = ddrl_roundup(nd.d_[l], 4);
-    nd.offw_[l] = off; off += nd.d_[l + 1] * nd.kp_[l];
+    nd.offw_[l] = off; off += ddrl_wsize(nd.d_[l + 1], nd.kp_[l]);
     nd.offb_[l] = off; off += ddrl_roundup(nd.d_[l + 1], 4);
     np += nd.d_[l + 1] * nd.d_[l] + nd.d_[l + 1];
   }
@@ -111,7 +111,7 @@ static void pack_flat(const NetDesc &nd, const double *flat, float *img) {
   size_t k = 0;
   for (int l = 0; l < nd.L(); ++l) {
     for (int n = 0; n < nd.d(l + 1); ++n)
-      for (int c = 0; c < nd.d(l); ++c) img[nd.offw(l) + n * nd.kp(l) + c] = (float)flat[k++];
+      for (int c = 0; c < nd.d(l); ++c) img[nd.offw(l) + ddrl_widx(n, c, nd.kp(l))] = (float)flat[k++];
     for (int n = 0; n < nd.d(l + 1); ++n) img[nd.offb(l) + n] = (float)flat[k++];
   }
 }
@@ -119,7 +119,7 @@ static void unpack_flat(const NetDesc &nd, const float *img, double *flat) {
   size_t k = 0;
   for (int l = 0; l < nd.L(); ++l) {
     for (int n = 0; n < nd.d(l + 1); ++n)
-      for (int c = 0; c < nd.d(l); ++c) flat[k++] = (double)img[nd.offw(l) + n * nd.kp(l) + c];
+      for (int c = 0; c < nd.d(l); ++c) flat[k++] = (double)img[nd.offw(l) + ddrl_widx(n, c, nd.kp(l))];
     for (int n = 0; n < nd.d(l + 1); ++n) flat[k++] = (double)img[nd.offb(l) + n];
   }
 }

@@ -25,9 +25,23 @@ __host__ __device__ constexpr int ddrl_ldpad(int n) {
   return r;
 }
 
+// Weight storage of one layer, [N x kp] with kp = roundup(K, 4): TILE-MAJOR.  Rows are grouped in
+// strips of 16 (the last strip padded with zero rows); inside a strip the 16-column blocks follow
+// each other, each block stored row-major [16 x kw] with kw = min(16, kp - 16 kt).  A full block
+// is therefore 1 KiB of contiguous memory in exactly the lane order of a 16 x 16 MFMA accumulator
+// tile (lane (c, g) <-> row c, floats 4g..4g+3), so the fused optimiser's seven loads and five
+// stores per tile are each one contiguous 1-KiB wave access (measured with tools/membench.hip:
+// 4.9 TB/s against 3.4 TB/s and 1.33x over-fetch for row-major 64-byte row segments), and the
+// forward pass's weight fragments are contiguous too.  Pad rows/columns hold 0 and stay 0.
+__host__ __device__ constexpr int ddrl_tile_kw(int kt, int kp) { return kp - kt * 16 < 16 ? kp - kt * 16 : 16; }
+__host__ __device__ constexpr int ddrl_tile_base(int nt, int kt, int kp) { return nt * 16 * kp + kt * 256; }
+__host__ __device__ constexpr int ddrl_widx(int n, int k, int kp) {
+  return ddrl_tile_base(n >> 4, k >> 4, kp) + (n & 15) * ddrl_tile_kw(k >> 4, kp) + (k & 15);
+}
+__host__ __device__ constexpr int ddrl_wsize(int N, int kp) { return ddrl_roundup(N, 16) * kp; }
+
 // One MLP's shape and its padded device layout.  Per agent the net is one block of `stride`
-// floats: layer l weights at offw(l), row-major [d(l+1) x kp(l)] with kp = roundup(d(l), 4) so that
-// every row starts 16-byte aligned (pad columns hold 0 and stay 0), bias at offb(l).
+// floats: layer l weights at offw(l) (tile-major, above), bias at offb(l).
 // Two providers with the same accessors: NetDesc (run-time shapes, the generic kernels) and
 // SNet<...> (compile-time shapes: every loop bound, guard and offset folds to a constant).
 struct NetDesc {
@@ -60,10 +74,10 @@ struct SNet {
   __host__ __device__ static constexpr int ld(int i) { return ddrl_ldpad(d(i)); }
   __host__ __device__ static constexpr int offw(int l) {
     int off = 0;
-    for (int i = 0; i < l; ++i) off += d(i + 1) * kp(i) + ddrl_roundup(d(i + 1), 4);
+    for (int i = 0; i < l; ++i) off += ddrl_wsize(d(i + 1), kp(i)) + ddrl_roundup(d(i + 1), 4);
     return off;
   }
-  __host__ __device__ static constexpr int offb(int l) { return offw(l) + d(l + 1) * kp(l); }
+  __host__ __device__ static constexpr int offb(int l) { return offw(l) + ddrl_wsize(d(l + 1), kp(l)); }
   __host__ __device__ static constexpr int stride() { return ddrl_roundup(offw(NL), 64); }
   __host__ __device__ static constexpr int hidden_act() { return HACT; }
   __host__ __device__ static constexpr int out_act() { return OACT; }
