@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two w
 ddpg_update_kernel(const DdpgParams P) {
   extern __shared__ __align__(16) float lds[];
   const int agent = blockIdx.x;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform, waits are counted exactly
   if (P.mask && !P.mask[agent]) return;
   const int len = P.rep_len[agent], head = P.rep_head[agent];
   if (len < 250 || len < P.B) return;                      // DeepQNAg.hpp:338

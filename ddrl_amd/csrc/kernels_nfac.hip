@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(DDRL_NTHREADS)
 nfac_values_kernel(const NfacParams P) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform, waits are counted exactly
   if (P.mask && !P.mask[agent]) return;
   const int T = P.len[agent], row0 = chunk * DDRL_MB;
   if (row0 >= T) return;
@@ -130,7 +131,8 @@ __global__ void __launch_bounds__(DDRL_NTHREADS)
 nfac_grad_kernel(const NfacParams P) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform, waits are counted exactly
   if (P.mask && !P.mask[agent]) return;
   const int T = P.len[agent], row0 = chunk * DDRL_MB;
   if (row0 >= T) return;

@@ -7,6 +7,13 @@
 // bit-for-bit an fp32 fma chain (cdna_hip_programming.md section 3), so results do not depend on
 // tile shapes beyond the order of the k-sum.
 //
+// Forward passes and input-gradient (dX) passes are ROW-PARALLEL: wave w owns batch rows
+// 16w .. 16w+15 and carries them through every layer by itself (all output column tiles), so a
+// whole pass needs no workgroup barrier, every wave issues the same number of MFMAs whatever the
+// layer width (a 1-wide critic output costs a quarter tile per wave, not a full tile on one
+// wave), and the activation fragments are read from LDS once per layer instead of once per
+// column tile.  Only the dW products contract over all 64 rows and synchronise the workgroup.
+//
 // Every function takes the layer shape as plain ints.  Called from a kernel instantiated on a
 // compile-time net (SNet<...>) they arrive as constants and all guards / loop bounds fold; called
 // from the generic kernel (NetDesc) the same source handles any shape up to DDRL_MAXW.
@@ -22,6 +29,14 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+// Hides a (uniform) pointer's provenance from the optimiser: the same weights are walked by several
+// passes of one kernel, and without this the per-lane addresses of ALL passes are computed once,
+// kept alive across the whole kernel and spilled (150 64-bit values in the mid-size DDPG kernel).
+__device__ __forceinline__ const float *opaque(const float *p) {
+  int z = 0;
+  asm volatile("" : "+s"(z));      // an offset of 0 the optimiser cannot see; the address space of p is kept
+  return p + z;
+}
 
 // Caffe ReLULayer (negative_slope 0.01 for hidden_layer_type 1, MLP.hpp:888-897), TanHLayer
 __device__ __forceinline__ float act_fwd(int t, float x) {
@@ -46,134 +61,158 @@ __device__ __forceinline__ float act_bwd(int t, float y, float dy) {
 // of W, columns kc*16 + 4g .. + 3 for every 16-deep k-chunk kc.  Requested in one burst so the
 // L2/HBM latency is paid once per tile; callers request the NEXT tile's fragments (also across a
 // layer boundary: weights do not depend on activations) before computing the current one.
-struct BFrag { f32x4 v[DDRL_MAXKC]; };
+struct BFrag { f32x4 v[DDRL_MAXKC]; float bias; };   // + the tile's bias: waiting for it separately would drain the prefetches (loads retire in order)
 
-__device__ __forceinline__ void load_bfrag(const float *__restrict__ W, int kp, int N, int nt, int lane, BFrag &b) {
+__device__ __forceinline__ void load_bfrag(const float *__restrict__ W, const float *__restrict__ bias, int kp, int N, int nt, int lane, BFrag &b) {
   const int g = lane >> 4, c = lane & 15;
+  b.bias = bias[nt * 16 + c < N ? nt * 16 + c : N - 1];
   // tile-major storage: block (nt, kc) is contiguous and lane (c, g)'s float4 sits at c*kw + 4g, so
   // a full block is one 1-KiB wave load.  Pad rows (n >= N) exist in memory and hold zeros.
-  // No divergent branch around a load: the address is clamped into the block and the value masked
-  // afterwards, so the compiler can count the outstanding loads exactly (a load inside a lane-
-  // dependent branch makes it fall back to s_waitcnt vmcnt(0) at the join)
+  // No divergent branch around a load (the compiler would fall back to s_waitcnt vmcnt(0) at the
+  // join): the address is clamped into the block.
 #pragma unroll
   for (int kc = 0; kc < DDRL_MAXKC; ++kc) {
     if (kc * 16 < kp) {                       // uniform (folds for compile-time shapes)
       const int kw = ddrl_tile_kw(kc, kp);
       const float *blk = W + ddrl_tile_base(nt, kc, kp) + c * kw;
-      const f32x4 v = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
-      b.v[kc] = (kw == 16 || 4 * g < kw) ? v : zero4();
+      b.v[kc] = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));   // k >= kp: finite filler, meets a zero A column
     }
   }
 }
 
-// One 64 x 16 output tile of Y = act(X W^T + b).  Xs: LDS, row stride ldx, columns [K, kp) hold
-// zeros.  Ys: LDS, row stride ldy; columns [N, roundup(N,4)) are zeroed.
-__device__ __forceinline__ void fwd_tile(const float *__restrict__ Xs, int ldx, int kp, const BFrag &b,
-                                         const float *__restrict__ bias, int N, int act,
-                                         float *__restrict__ Ys, int ldy, int nt, int lane) {
+static_assert(DDRL_NWAVES * 16 == DDRL_MB, "row-parallel passes: one 16-row tile per wave");
+
+// The activation fragments of this wave's 16 rows for a whole layer input: row 16w + c, columns
+// kc*16 + 4g .. + 3 for every 16-deep k-chunk.  Columns >= kp are zeroed HERE (one LDS-side select per
+// layer), so the weight fragments they meet need no masking: masking a prefetched global load would
+// force a wait for it right where it is issued.
+struct AFrag { f32x4 v[DDRL_MAXKC]; };
+
+__device__ __forceinline__ void load_afrag(const float *__restrict__ Xs, int ldx, int kp, int wave, int lane, AFrag &a) {
   const int g = lane >> 4, c = lane & 15;
-  const int n = nt * 16 + c;
-  const float bv = bias[n < N ? n : N - 1];
-  f32x4 acc[4];
+  const float *row = Xs + (16 * wave + c) * ldx;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) acc[mt] = zero4();
-#pragma unroll
-  for (int kc = 0; kc < DDRL_MAXKC; ++kc) {
+  for (int kc = 0; kc < DDRL_MAXKC; ++kc)
     if (kc * 16 < kp) {
-      // columns >= kp of this chunk meet zero weight fragments: read a clamped (valid, finite) column
-      const int k = kc * 16 + 4 * g < kp ? kc * 16 + 4 * g : kp - 4;
+      const bool in = kc * 16 + 4 * g < kp;
+      const f32x4 v = *(const f32x4 *)(row + (in ? kc * 16 + 4 * g : kp - 4));
+      a.v[kc] = (kc * 16 + 16 <= kp || in) ? v : zero4();
+    }
+}
+
+// one 16 x 16 tile: rows of this wave x output columns nt*16 .. +15.  Two accumulators over the
+// parity of the k-chunk keep two independent MFMA chains in flight (dependent-issue latency of
+// v_mfma_f32_16x16x4_f32 is 40 cycles against 32 for independent ones).
+__device__ __forceinline__ f32x4 row_tile(const AFrag &a, const BFrag &b, int kp) {
+  f32x4 acc0 = zero4(), acc1 = zero4();
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 a = *(const f32x4 *)(Xs + (mt * 16 + c) * ldx + k);
-        acc[mt] = mfma16(a[0], b.v[kc][0], acc[mt]);
-        acc[mt] = mfma16(a[1], b.v[kc][1], acc[mt]);
-        acc[mt] = mfma16(a[2], b.v[kc][2], acc[mt]);
-        acc[mt] = mfma16(a[3], b.v[kc][3], acc[mt]);
+  for (int kc = 0; kc < DDRL_MAXKC; kc += 2) {
+    if (kc * 16 < kp) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = mfma16(a.v[kc][e], b.v[kc][e], acc0);
+        if ((kc + 1) * 16 < kp) acc1 = mfma16(a.v[kc + 1][e], b.v[kc + 1][e], acc1);
       }
     }
   }
-  if (n < ldy) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + 4 * g + r;
-        Ys[row * ldy + n] = n < N ? act_fwd(act, acc[mt][r] + bv) : 0.f;
-      }
-  }
+  return acc0 + acc1;
 }
 
-// Y[64 x N] = act(X W^T + b) for one layer, wave w owning column tiles w, w+NWAVES, ... (all four row
-// tiles each, so W is read once).  have/b0: fragments of this wave's first tile if already
-// requested by the caller.  nextW != null: once the last tile's fragments are in flight, request
-// the first tile of the next layer (returned in b0 with have = true).
+// Y[rows of this wave][N] = act(X W^T + b) for one layer.  Xs / Ys: LDS, 64 rows; columns
+// [N, ldy) of Ys are zeroed.  The next column tile's weight fragments are in flight while the
+// current tile is computed.
 __device__ __forceinline__ void fwd_layer(const float *__restrict__ Xs, int ldx, int kp,
                                           const float *__restrict__ W, const float *__restrict__ bias,
-                                          int N, int act, float *__restrict__ Ys, int ldy,
-                                          int wave, int lane, BFrag &b0, bool &have,
-                                          const float *__restrict__ nextW, int next_kp, int nextN) {
+                                          int N, int act, float *__restrict__ Ys, int ldy, int wave, int lane) {
+  const int g = lane >> 4, c = lane & 15;
   const int NT = (N + 15) >> 4;
-  if (!have && wave < NT) load_bfrag(W, kp, N, wave, lane, b0);
-  have = false;
-  const bool next_mine = nextW && wave < ((nextN + 15) >> 4);
-  // two fragment sets with static names (a register copy would wait for the loads it copies)
-  BFrag b1;
-  for (int nt = wave; nt < NT; nt += 2 * DDRL_NWAVES) {
-    const int nt1 = nt + DDRL_NWAVES, nt2 = nt1 + DDRL_NWAVES;
-    if (nt1 < NT) load_bfrag(W, kp, N, nt1, lane, b1);
-    else if (next_mine) load_bfrag(nextW, next_kp, nextN, wave, lane, b1);
-    fwd_tile(Xs, ldx, kp, b0, bias, N, act, Ys, ldy, nt, lane);
-    if (nt1 < NT) {
-      if (nt2 < NT) load_bfrag(W, kp, N, nt2, lane, b0);
-      else if (next_mine) { load_bfrag(nextW, next_kp, nextN, wave, lane, b0); have = true; }
-      fwd_tile(Xs, ldx, kp, b1, bias, N, act, Ys, ldy, nt1, lane);
-    } else if (next_mine) {
-      b0 = b1;       // odd tile count: the next layer's fragments landed in b1
-      have = true;
+  W = opaque(W);
+  bias = opaque(bias);
+  AFrag a;
+  load_afrag(Xs, ldx, kp, wave, lane, a);
+  // three fragment sets in rotation: the loads for tile nt + 2 are issued before tile nt is
+  // computed (one tile of MFMAs, ~900 cycles, does not cover an L2 round trip under load)
+  BFrag b0, b1, b2;
+  load_bfrag(W, bias, kp, N, 0, lane, b0);
+  if (1 < NT) load_bfrag(W, bias, kp, N, 1, lane, b1);
+  float *yrow = Ys + (16 * wave + 4 * g) * ldy;
+  auto store = [&](int nt, const f32x4 acc, const float bv) {
+    const int n = nt * 16 + c;
+    if (n < ldy) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yrow[r * ldy + n] = n < N ? act_fwd(act, acc[r] + bv) : 0.f;
+    }
+  };
+  // a real loop: fully unrolled, the scheduler hoists every tile's weight loads and spills
+#pragma unroll 1
+  for (int nt = 0; nt < NT; nt += 3) {
+    if (nt + 2 < NT) load_bfrag(W, bias, kp, N, nt + 2, lane, b2);
+    store(nt, row_tile(a, b0, kp), b0.bias);
+    if (nt + 1 < NT) {
+      if (nt + 3 < NT) load_bfrag(W, bias, kp, N, nt + 3, lane, b0);
+      store(nt + 1, row_tile(a, b1, kp), b1.bias);
+    }
+    if (nt + 2 < NT) {
+      if (nt + 4 < NT) load_bfrag(W, bias, kp, N, nt + 4, lane, b1);
+      store(nt + 2, row_tile(a, b2, kp), b2.bias);
     }
   }
 }
 
-// dX[64 x cols] = dY[64 x N] W[N x kp], for column tiles kt in [kt0, kt1); wave w owns tiles
-// kt0 + w + NWAVES i, i < MAXKT, results stay in registers (acc[i][mt]).  dYs: LDS, columns [N, roundup
-// (N,4)) must hold zeros.  The weight fragments of a tile are requested in one burst.
-template <int MAXKT>
+// dX[rows of this wave][cols] = dY W for the column tiles kt in [kt0, kt1), kept in registers
+// (acc[kt - kt0]).  dYs: LDS, columns [N, roundup(N,4)) hold zeros.  B operand of tile (nc, kt): lane
+// (c, g) supplies W[nc*16 + 4g + j][kt*16 + c], four dword loads inside one contiguous 1-KiB block.
+struct WCol { float v[DDRL_MAXKC][4]; };
+
+__device__ __forceinline__ void load_wcol(const float *__restrict__ W, int kp, int N, int kt, int lane, WCol &b) {
+  const int g = lane >> 4, c = lane & 15;
+  const int kw = ddrl_tile_kw(kt, kp);
+  const int cc = c < kw ? c : kw - 1;                  // clamp: columns >= kp are discarded by the caller
+#pragma unroll
+  for (int nc = 0; nc < DDRL_MAXKC; ++nc)
+    if (nc * 16 < N) {
+      const float *blk = W + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + cc;   // pad rows (n >= N) hold zeros
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b.v[nc][j] = blk[j * kw];
+    }
+}
+
+__device__ __forceinline__ f32x4 dx_tile(const AFrag &a, const WCol &b, int N) {
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+  for (int nc = 0; nc < DDRL_MAXKC; nc += 2) {
+    if (nc * 16 < N) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = mfma16(a.v[nc][e], b.v[nc][e], acc0);
+        if ((nc + 1) * 16 < N) acc1 = mfma16(a.v[nc + 1][e], b.v[nc + 1][e], acc1);
+      }
+    }
+  }
+  return acc0 + acc1;
+}
+
 __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, int N,
                                        const float *__restrict__ W, int kp, int kt0, int kt1,
-                                       f32x4 (&acc)[MAXKT][4], int wave, int lane) {
-  const int g = lane >> 4, c = lane & 15;
-  const int n4 = ddrl_roundup(N, 4);
+                                       f32x4 (&acc)[DDRL_MAXKC], int wave, int lane) {
+  W = opaque(W);
+  AFrag a;
+  load_afrag(dYs, ldy, ddrl_roundup(N, 4), wave, lane, a);
+  WCol b0, b1;
+  if (kt0 < kt1) load_wcol(W, kp, N, kt0, lane, b0);
 #pragma unroll
-  for (int i = 0; i < MAXKT; ++i) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[i][mt] = zero4();
-    const int kt = kt0 + wave + DDRL_NWAVES * i;
+  for (int i = 0; i < DDRL_MAXKC; i += 2) {
+    const int kt = kt0 + i;
     if (kt < kt1) {
-      const int kw = ddrl_tile_kw(kt, kp);
-      const int cc = c < kw ? c : kw - 1;              // clamp: columns >= kp are discarded
-      float b[DDRL_MAXKC][4];
-#pragma unroll
-      for (int nc = 0; nc < DDRL_MAXKC; ++nc)
-        if (nc * 16 < N) {
-          // block (nc, kt) of the tile-major weights; pad rows (nn >= N) are stored and hold zeros
-          const float *blk = W + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + cc;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b[nc][j] = blk[j * kw];
-        }
-#pragma unroll
-      for (int nc = 0; nc < DDRL_MAXKC; ++nc) {
-        if (nc * 16 < N) {
-          // dY columns >= roundup(N,4) meet zero weights: read a clamped (valid, finite) column
-          const int nn = nc * 16 + 4 * g < n4 ? nc * 16 + 4 * g : n4 - 4;
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 a = *(const f32x4 *)(dYs + (mt * 16 + c) * ldy + nn);
-            acc[i][mt] = mfma16(a[0], b[nc][0], acc[i][mt]);
-            acc[i][mt] = mfma16(a[1], b[nc][1], acc[i][mt]);
-            acc[i][mt] = mfma16(a[2], b[nc][2], acc[i][mt]);
-            acc[i][mt] = mfma16(a[3], b[nc][3], acc[i][mt]);
-          }
-        }
+      // acc[] needs static indices, so this loop is unrolled; the scheduling barriers keep the
+      // loads of later tiles from being hoisted above the products of this one (spills otherwise)
+      if (kt + 1 < kt1) load_wcol(W, kp, N, kt + 1, lane, b1);
+      acc[i] = dx_tile(a, b0, N);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < kt1) {
+        if (kt + 2 < kt1) load_wcol(W, kp, N, kt + 2, lane, b0);
+        acc[i + 1] = dx_tile(a, b1, N);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

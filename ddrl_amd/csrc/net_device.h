@@ -25,39 +25,45 @@ __device__ __forceinline__ void bwd_dw_store(const float *__restrict__ dYs, int 
   }
 }
 
+// a wave's LDS stores must have landed before the same wave's later loads of other lanes' values
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // forward through layers [0, nl) of a net; hidden activation l goes to hbase + (l-1)*hstride, the
-// output of the last InnerProduct (when nl == L) to top
+// output of the last InnerProduct (when nl == L) to top.  Row-parallel: every wave walks its own 16
+// rows through all layers; one workgroup barrier at the end publishes the results.
 template <class ND>
 __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__restrict__ w,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                         int wave, int lane) {
   const float *in = X;
   int ldi = ldx;
-  BFrag b0;
-  bool have = false;
 #pragma unroll
   for (int l = 0; l < nd.L(); ++l) {
     if (l < nl) {
       const bool last = l == nd.L() - 1;
-      const bool more = l + 1 < nl;
-      const int ln = more ? l + 1 : l;       // keeps the accessors in range when there is no next layer
       float *out = last ? top : hbase + l * hstride;
       const int ldo = last ? ldtop : nd.ld(l + 1);
       fwd_layer(in, ldi, nd.kp(l), w + nd.offw(l), w + nd.offb(l), nd.d(l + 1),
-                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane, b0, have,
-                more ? w + nd.offw(ln) : nullptr, more ? nd.kp(ln) : 0, more ? nd.d(ln + 1) : 0);
-      __syncthreads();
+                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane);
+      wave_lds_fence();
       in = out;
       ldi = ldo;
     }
   }
+  __syncthreads();
 }
 
 // Backward through a whole net from dZ_L held in `top` (diff w.r.t. the last InnerProduct's
-// output).  DW_OPT: parameter gradients go through the fused optimiser epilogue (with a target twin).
+// output; the caller has synchronised the workgroup after writing it).  The dX chain is row-
+// parallel (no barrier); the dW products contract over all 64 rows and are bracketed by barriers.
+// DW_OPT: parameter gradients go through the fused optimiser epilogue (with a target twin).
 // DW_STORE: they are written to gout (one agent-net image, same layout as the weights) for a later
 // reduction over batch chunks.  nc > 0: the input gradient columns [c0, c0 + nc) are handed to
-// dx0_store(row, col - c0, value).
+// dx0_store(row, col - c0, value); the caller synchronises before other waves read what it wrote.
 enum { DW_NONE = 0, DW_OPT = 1, DW_STORE = 2 };
 template <int TRAIN, bool EWC, class ND, class DX0>
 __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w, const OptCtx opt, float *gout,
@@ -74,36 +80,34 @@ __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w
     float *in = l == 0 ? const_cast<float *>(X) : hbase + (l - 1) * hstride;
     const int ldi = l == 0 ? ldx : nd.ld(l);
     const bool need_dx = l > 0 || nc > 0;
-    f32x4 acc[DDRL_MAXKT][4];
+    f32x4 acc[DDRL_MAXKC];
     int kt0 = 0, kt1 = (K + 15) >> 4;
     if (l == 0) { kt0 = c0 >> 4; kt1 = (c0 + nc + 15) >> 4; }
-    if (need_dx) bwd_dx<DDRL_MAXKT>(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
-    if (TRAIN == DW_OPT) {
-      __syncthreads();   // every wave has read W_l before any wave's epilogue rewrites it
-      bwd_dw_opt<EWC, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+    if (need_dx) bwd_dx(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
+    if (TRAIN != DW_NONE) {
+      __syncthreads();   // every wave's rows of dZ_l are final and every wave has read W_l
+      if (TRAIN == DW_OPT) bwd_dw_opt<EWC, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+      else bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid);
+      __syncthreads();   // every wave has read H_{l-1} before its rows are overwritten by dZ_{l-1}
     }
-    if (TRAIN == DW_STORE) bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid);
-    __syncthreads();     // every wave has read H_l before it is overwritten by dZ_l
     if (need_dx) {
 #pragma unroll
-      for (int i = 0; i < DDRL_MAXKT; ++i) {
-        const int kt = kt0 + wave + DDRL_NWAVES * i;
+      for (int i = 0; i < DDRL_MAXKC; ++i) {
+        const int kt = kt0 + i;
         if (kt < kt1) {
           const int col = kt * 16 + c;
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = mt * 16 + 4 * g + r;
-              if (l > 0) {
-                if (col < K) in[row * ldi + col] = act_bwd(nd.hidden_act(), in[row * ldi + col], acc[i][mt][r]);
-              } else if (col >= c0 && col < c0 + nc) {
-                dx0_store(row, col - c0, acc[i][mt][r]);
-              }
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + 4 * g + r;
+            if (l > 0) {
+              if (col < K) in[row * ldi + col] = act_bwd(nd.hidden_act(), in[row * ldi + col], acc[i][r]);
+            } else if (col >= c0 && col < c0 + nc) {
+              dx0_store(row, col - c0, acc[i][r]);
             }
+          }
         }
       }
-      __syncthreads();
+      wave_lds_fence();
     }
     dZ = in;
     ldz = ldi;
