@@ -1,0 +1,34 @@
+"""world_size-2 gloo worker for tests/test_shard_cpu.py (CPU only: the oracle stands in for the GPU
+Cmaes object; what is under test is the sharding + all-gather logic of ddrl_amd/shard.py)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out, lam, N, gens = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from oracle import oracle as ora
+    from ddrl_amd.shard import ShardedCmaes, agent_seeds, block_range
+    es = ora.Cmaes(0.1 * (np.arange(N) + 1), [0.5] * N, 3, lam)
+    sh = ShardedCmaes(es, lam, rank, world, device="cpu")
+    fits = []
+    for _ in range(gens):
+        fits.append(sh.generation(lambda x: float(np.sum(x * x))).tolist())
+    res = dict(rank=rank, world=world, block=block_range(lam, rank, world), sigma=es.get("sigma"),
+               xmean=es.vec("xmean").tolist(), index=es.index().tolist(), fits=fits,
+               seeds=agent_seeds(1000, 37, rank, world).tolist())
+    with open("%s.%d" % (out, rank), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
