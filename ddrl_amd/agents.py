@@ -1,0 +1,113 @@
+"""Python mirror of the agent-level front end (ddrl_agents_* and the reference's own DDPGAg_* names,
+include/ddrl_pop.h).  DDRLAg follows gym/agent.py:120-157 of the reference call for call."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+from .population import Population, _p
+
+
+class _Borrowed(Population):
+    """the population owned by a front end (not destroyed with this view)"""
+
+    def __init__(self, L, handle, G, S, A):
+        self.L, self.h, self.G, self.S, self.A = L, handle, G, S, A
+
+    def close(self):
+        self.h = None
+
+    __del__ = close
+
+
+class DdpgAgents:
+    """G DDPG agents driven step by step: ARLAgent::runf + DeepQNAg::_run for every agent per call."""
+
+    def __init__(self, ini_path, n_agents, nb_sensors, nb_motors, seed=0, device=-1):
+        self.L = _l.load()
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_agents_create_ddpg(ini_path.encode(), n_agents, nb_sensors, nb_motors, device, seed, C.byref(h)))
+        self.h, self.G, self.S, self.A = h, n_agents, nb_sensors, nb_motors
+        self.pop = _Borrowed(self.L, C.c_void_p(self.L.ddrl_agents_population(h)), n_agents, nb_sensors, nb_motors)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.pop.close()
+            self.L.ddrl_agents_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _flags(self, x):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.uint8), (self.G,)))
+
+    def _mask(self, m):
+        return None if m is None else np.ascontiguousarray(m, np.uint8).reshape(self.G)
+
+    def start_episode(self, states, learning=True, mask=None):
+        s = np.ascontiguousarray(states, np.float32).reshape(self.G, self.S)
+        _l.check(self.L.ddrl_agents_start_episode(self.h, _p(s), _p(self._flags(learning)), _p(self._mask(mask))))
+
+    def run(self, reward, states, learning=True, goal=False, last=False, mask=None):
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(reward, np.float32), (self.G,)))
+        s = np.ascontiguousarray(states, np.float32).reshape(self.G, self.S)
+        out = np.empty((self.G, self.A), np.float32)
+        _l.check(self.L.ddrl_agents_run(self.h, _p(r), _p(s), _p(self._flags(learning)), _p(self._flags(goal)),
+                                        _p(self._flags(last)), _p(self._mask(mask)), _p(out)))
+        return out
+
+    def end_episode(self, learning=True, mask=None):
+        _l.check(self.L.ddrl_agents_end_episode(self.h, _p(self._flags(learning)), _p(self._mask(mask))))
+
+    def stats(self):
+        swr, sr, ep = np.empty(self.G), np.empty(self.G), np.empty(self.G, np.int32)
+        _l.check(self.L.ddrl_agents_stats(self.h, _p(swr), _p(sr), _p(ep)))
+        return dict(sum_weighted_reward=swr, sum_reward=sr, episode=ep)
+
+
+class DDRLAg:
+    """gym/agent.py's DDRLAg against libddrl_pop.so: same methods, same DDPGAg_* calls."""
+
+    def __init__(self, nb_motors, nb_sensors, argv=()):
+        self.L = _l.load()
+        self.nb_motors, self.nb_sensors = nb_motors, nb_sensors
+        self.obj = self.L.DDPGAg_new(nb_motors, nb_sensors)
+        argv = list(argv) + [""]
+        arr = (C.c_char_p * len(argv))(*[a.encode("utf-8") for a in argv])
+        self.L.DDPGAg_unique_invoke(self.obj, len(argv), arr)
+
+    def run(self, reward, state, learning, goal, last):
+        s = np.ascontiguousarray(state, np.float64)
+        p = self.L.DDPGAg_run(self.obj, reward, s.ctypes.data, learning, goal, last)
+        if not p:
+            raise _l.DdrlError(-1, self.L.ddrl_last_error().decode(errors="replace"))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(self.nb_motors,)).copy()
+
+    def start_ep(self, state, learning):
+        s = np.ascontiguousarray(state, np.float64)
+        self.L.DDPGAg_start_episode(self.obj, s.ctypes.data, learning)
+
+    def end_ep(self, learning):
+        self.L.DDPGAg_end_episode(self.obj, learning)
+
+    def dump(self, learning, episode, step, treward):
+        self.L.DDPGAg_dump(self.obj, learning, episode, step, treward)
+
+    def display(self, learning, episode, step, treward):
+        self.L.DDPGAg_display(self.obj, learning, episode, step, treward)
+
+    def save(self, episode):
+        self.L.DDPGAg_save(self.obj, episode)
+
+    def load(self, episode):
+        self.L.DDPGAg_load(self.obj, episode)
+
+    def name(self):
+        return "DDPG"
+
+    def close(self):
+        if getattr(self, "obj", None):
+            self.L.DDPGAg_delete(self.obj)
+            self.obj = None
+
+    __del__ = close

@@ -1,0 +1,395 @@
+// agents.hip -- the agent-level front end over a DDPG population: what ARLAgent::runf /
+// start_episode (common/include/arch/ARLAgent.hpp:37-137) and DeepQNAg::_run / _start_episode /
+// end_episode / end_instance (agent/deepqn/include/DeepQNAg.hpp:122-165, 237-317) do around the nets,
+// for G agents at once, plus the G = 1 C flavour with the reference's own names and argument types
+// (DDPGAg_*, agent/deepqn/src/pybinding/ddpg.cpp:9-88; caller gym/agent.py:112-157).
+//
+// Host code only: decision_each / reward max-pooling / discounted-return bookkeeping and the
+// exploration noise (SURVEY.md 8a row a32 keeps it on the host).  Every net evaluation, replay
+// insertion and update goes through the ddrl_pop_* entry points, i.e. runs on the GPU.
+#include "pop_host.h"
+
+#include <memory>
+
+struct AgentState {
+  std::vector<double> inter_rewards;
+  int time_for_ac = 1;
+  double global_pow_gamma = 1., sum_weighted_reward = 0., sum_reward = 0., last_sum_weighted_reward = 0.;
+  double last_receive_reward = 0.;
+  bool last_episode_learning = false, have_last = false;
+  int episode = 0, step = 0;
+  std::vector<double> ou_x;                  // OrnsteinUhlenbeckNoise::x_t
+  std::mt19937 engine;
+};
+
+struct ddrl_agents {
+  ddrl_pop *pop = nullptr;
+  int G = 0, S = 0, A = 0;
+  double gamma = 0.99, noise = 0., noise2 = 0., noise3 = 0., reward_scale = 1.;
+  int gaussian_policy = 0, decision_each = 1, force_more_update = 0;
+  std::vector<AgentState> ag;
+  std::vector<float> last_state, last_action, returned_ac, pure, rew;   // [G x S], [G x A], [G x A], [G x A], [G]
+  std::vector<uint8_t> insert_mask, goal;
+  std::vector<double> ret_double;            // DDPGAg_run's return buffer (valid until the next call)
+};
+
+// N(mu, sigma) truncated to [a, b].  The reference calls Chopin's table-driven rtnorm
+// (common/src/RTNorm.cpp) on its clock-seeded engine; its stream cannot be pinned, so this is the
+// same distribution by rejection sampling (Robert 1995 for the tails), not the same stream.
+static double trunc_normal(std::mt19937 &eng, double a, double b, double mu, double sigma) {
+  std::uniform_real_distribution<double> U(0., 1.);
+  if (!(sigma > 0.)) return std::min(std::max(mu, a), b);
+  const double al = (a - mu) / sigma, be = (b - mu) / sigma;
+  auto tail = [&](double lo, double hi) {      // lo > 0: exponential proposal
+    const double lam = 0.5 * (lo + std::sqrt(lo * lo + 4.));
+    for (;;) {
+      const double z = lo - std::log(1. - U(eng)) / lam;
+      if (z <= hi && U(eng) <= std::exp(-0.5 * (z - lam) * (z - lam))) return z;
+    }
+  };
+  double z;
+  if (al > 2.) z = tail(al, be);
+  else if (be < -2.) z = -tail(-be, -al);
+  else if (be - al > 1.5) {
+    std::normal_distribution<double> Nn(0., 1.);
+    do z = Nn(eng); while (z < al || z > be);
+  } else {                                     // narrow central interval: uniform proposal
+    const double m = (al <= 0. && be >= 0.) ? 0. : std::min(std::fabs(al), std::fabs(be));
+    for (;;) {
+      z = al + (be - al) * U(eng);
+      if (U(eng) <= std::exp(-0.5 * (z * z - m * m))) break;
+    }
+  }
+  return mu + sigma * z;
+}
+
+// the learning branch of DeepQNAg::_run's action perturbation (DeepQNAg.hpp:134-145)
+static void explore(ddrl_agents *h, int g, float *act) {
+  AgentState &s = h->ag[g];
+  const int A = h->A;
+  if (h->gaussian_policy == 1) {               // multidimentionnalTruncatedGaussian (MetropolisHasting.hpp:31-46)
+    for (int i = 0; i < A; ++i) {
+      double mu = act[i];
+      if (mu > 1.0f + 3.f * h->noise) mu = 1.0f + 3.f * h->noise;
+      else if (mu < -1.0f - 3.f * h->noise) mu = -1.0f - 3.f * h->noise;
+      act[i] = (float)trunc_normal(s.engine, -1.0, 1.0, mu, h->noise);
+    }
+  } else if (h->gaussian_policy == 2) {        // OrnsteinUhlenbeckNoise::step (OrnsteinUhlenbeckNoise.hpp:22-37)
+    std::normal_distribution<double> dist(0., 1.);
+    for (int i = 0; i < A; ++i) {
+      const double normal = dist(s.engine);
+      const double x_tplus = s.ou_x[i] - h->noise2 * h->noise3 * s.ou_x[i] + h->noise * std::sqrt(h->noise3) * normal;
+      double m = act[i] + x_tplus;
+      if (m < -1.) m = -1.; else if (m > 1.) m = 1.;
+      act[i] = (float)m;
+      s.ou_x[i] = x_tplus;
+    }
+  } else {                                     // e-greedy (:141-144)
+    std::uniform_real_distribution<double> U(0., 1.);
+    if (U(s.engine) < h->noise)
+      for (int i = 0; i < A; ++i) act[i] = (float)(-1.f + U(s.engine) * 2.);
+  }
+}
+
+extern "C" int ddrl_agents_destroy(ddrl_agents_t *h) {
+  if (!h) return DDRL_OK;
+  if (h->pop) ddrl_pop_destroy(h->pop);
+  delete h;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int device,
+                                       uint64_t seed, ddrl_agents_t **out) {
+  if (!ini_path || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  *out = nullptr;
+  ddrl_ddpg_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.n_agents = n_agents; cfg.nb_sensors = nb_sensors; cfg.nb_motors = nb_motors; cfg.device = device;
+  int rc = ddrl_ddpg_config_from_ini(ini_path, &cfg);
+  if (rc) return rc;
+  std::unique_ptr<ddrl_agents> h(new ddrl_agents());
+  DdrlIni ini;
+  std::string err;
+  if (!ini.load(ini_path, &err)) return ddrl_fail(DDRL_EIO, "%s", err.c_str());
+  try {
+    h->gamma = cfg.gamma;
+    h->decision_each = (int)ini.get_long("agent.decision_each");          // ARLAgent.hpp:143
+    h->noise = ini.get_double("agent.noise");                             // DeepQNAg.hpp:170-171
+    h->gaussian_policy = (int)ini.get_long("agent.gaussian_policy");
+    if (ini.has("agent.reward_scale")) h->reward_scale = ini.get_double("agent.reward_scale");
+    if (ini.has("agent.history_size") && ini.get_long("agent.history_size") != 1)
+      return ddrl_fail(DDRL_EINVAL, "agent.history_size != 1 is not supported");
+    if (h->gaussian_policy == 2) {                                        // :203-207
+      h->noise2 = ini.get_double("agent.noise2");
+      h->noise3 = ini.get_double("agent.noise3");
+    }
+  } catch (const std::exception &e) {
+    return ddrl_fail(DDRL_EIO, "%s: %s", ini_path, e.what());
+  }
+  if (h->decision_each < 1) return ddrl_fail(DDRL_EINVAL, "agent.decision_each < 1");
+  if ((rc = ddrl_ddpg_create(&cfg, seed, &h->pop))) return rc;
+  const int G = cfg.n_agents, S = cfg.nb_sensors, A = cfg.nb_motors;
+  h->G = G; h->S = S; h->A = A;
+  h->force_more_update = cfg.force_more_update;
+  h->ag.resize(G);
+  std::vector<uint32_t> rs(G);
+  for (int g = 0; g < G; ++g) {
+    h->ag[g].engine.seed((uint32_t)(seed * 2654435761ull + 2u * g + 1u));
+    h->ag[g].ou_x.assign(A, 0.);
+    rs[g] = (uint32_t)(seed * 40503ull + 7919u * g + 17u);
+  }
+  if ((rc = ddrl_pop_seed_replay(h->pop, rs.data()))) { ddrl_agents_destroy(h.release()); return rc; }
+  h->last_state.assign((size_t)G * S, 0.f);
+  h->last_action.assign((size_t)G * A, 0.f);
+  h->returned_ac.assign((size_t)G * A, 0.f);
+  h->pure.assign((size_t)G * A, 0.f);
+  h->rew.assign(G, 0.f);
+  h->insert_mask.assign(G, 0);
+  h->goal.assign(G, 0);
+  h->ret_double.assign(A, 0.);
+  *out = h.release();
+  return DDRL_OK;
+}
+
+extern "C" ddrl_pop_t *ddrl_agents_population(ddrl_agents_t *h) { return h ? h->pop : nullptr; }
+
+// ARLAgent::start_episode (ARLAgent.hpp:109-137) + DeepQNAg::_start_episode (DeepQNAg.hpp:237-247)
+extern "C" int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states, const uint8_t *learning, const uint8_t *mask) {
+  if (!h || !states || !learning) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  for (int g = 0; g < h->G; ++g) {
+    if (mask && !mask[g]) continue;
+    AgentState &s = h->ag[g];
+    s.time_for_ac = 1;
+    s.inter_rewards.clear();
+    if (s.last_episode_learning) s.last_sum_weighted_reward = s.sum_weighted_reward;
+    s.sum_weighted_reward = 0.;
+    s.sum_reward = 0.;
+    s.last_episode_learning = learning[g] != 0;
+    s.global_pow_gamma = 1.;
+    memcpy(&h->last_state[(size_t)g * h->S], states + (size_t)g * h->S, h->S * sizeof(float));
+    std::fill(s.ou_x.begin(), s.ou_x.end(), 0.);
+    s.have_last = false;
+    s.step = 0;
+  }
+  return DDRL_OK;
+}
+
+// one update round = 1 + force_more_update passes of the fupd loop (DeepQNAg.hpp:341); the
+// replay-size guard (:338) is applied per agent on the device
+static int update_round(ddrl_agents *h, const uint8_t *mask) {
+  for (int f = 0; f < 1 + h->force_more_update; ++f) {
+    int rc = ddrl_pop_ddpg_update(h->pop, nullptr, mask);
+    if (rc) return rc;
+  }
+  return DDRL_OK;
+}
+
+// ARLAgent::runf (ARLAgent.hpp:37-74) around DeepQNAg::_run (DeepQNAg.hpp:122-157) for every agent
+// with mask[g] != 0; actions_out [G x A] (agents between two decisions get their previous action)
+extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const float *states, const uint8_t *learning,
+                               const uint8_t *goal, const uint8_t *last, const uint8_t *mask, float *actions_out) {
+  if (!h || !reward || !states || !learning || !goal || !last || !actions_out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  const int G = h->G, S = h->S, A = h->A;
+  std::vector<uint8_t> decide(G, 0);
+  bool any = false, any_insert = false;
+  for (int g = 0; g < G; ++g) {
+    h->insert_mask[g] = 0;
+    if (mask && !mask[g]) continue;
+    AgentState &s = h->ag[g];
+    s.inter_rewards.push_back(reward[g]);
+    s.time_for_ac--;
+    if (s.time_for_ac == 0 || goal[g] || last[g]) {
+      double r = *std::max_element(s.inter_rewards.begin(), s.inter_rewards.end());
+      if (goal[g]) r = reward[g];                   // the last reward when entering an absorbing state (:56-58)
+      s.last_receive_reward = r;
+      h->rew[g] = (float)(r * h->reward_scale);
+      h->goal[g] = goal[g] ? 1 : 0;
+      decide[g] = 1;
+      any = true;
+      if (s.have_last && learning[g]) { h->insert_mask[g] = 1; any_insert = true; }   // DeepQNAg.hpp:128-131
+    }
+  }
+  if (any) {
+    // next_action = ann_testing->computeOut(sensors) with the weights BEFORE this step's update (:126)
+    int rc = ddrl_pop_infer(h->pop, states, h->pure.data());
+    if (rc) return rc;
+    if (any_insert) {
+      // insertSample: push {last_state, last_action, sensors, reward, goal}, then end_episode(true) (:159-165)
+      if ((rc = ddrl_pop_replay_append(h->pop, h->last_state.data(), h->last_action.data(), h->rew.data(), states,
+                                       h->goal.data(), h->insert_mask.data()))) return rc;
+      if ((rc = update_round(h, h->insert_mask.data()))) return rc;
+    }
+    for (int g = 0; g < G; ++g) {
+      if (!decide[g]) continue;
+      AgentState &s = h->ag[g];
+      float *act = &h->returned_ac[(size_t)g * A];
+      memcpy(act, &h->pure[(size_t)g * A], A * sizeof(float));
+      if (learning[g]) explore(h, g, act);
+      memcpy(&h->last_action[(size_t)g * A], act, A * sizeof(float));
+      memcpy(&h->last_state[(size_t)g * S], states + (size_t)g * S, S * sizeof(float));
+      s.have_last = true;
+      s.step++;
+      s.time_for_ac = h->decision_each;
+      s.inter_rewards.clear();
+      s.sum_weighted_reward += s.last_receive_reward * s.global_pow_gamma;        // ARLAgent.hpp:68-70
+      s.sum_reward += s.last_receive_reward;
+      s.global_pow_gamma *= h->gamma;
+    }
+  }
+  memcpy(actions_out, h->returned_ac.data(), (size_t)G * A * sizeof(float));
+  return DDRL_OK;
+}
+
+// DDPGAg_end_episode = end_episode(learning) + end_instance(learning) (ddpg.cpp:52-55;
+// DeepQNAg.hpp:336-339, 290-317)
+extern "C" int ddrl_agents_end_episode(ddrl_agents_t *h, const uint8_t *learning, const uint8_t *mask) {
+  if (!h || !learning) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  const int G = h->G;
+  std::vector<uint8_t> lm(G, 0), tm(G, 0);
+  std::vector<double> score(G, 0.);
+  bool any_l = false, any_t = false;
+  for (int g = 0; g < G; ++g) {
+    if (mask && !mask[g]) continue;
+    score[g] = h->ag[g].sum_weighted_reward;
+    if (learning[g]) { lm[g] = 1; any_l = true; } else { tm[g] = 1; any_t = true; }
+  }
+  int rc;
+  if (any_l && (rc = update_round(h, lm.data()))) return rc;
+  const int method = h->pop->cfg.ewc_best_param_method;
+  if (h->pop->cfg.ewc >= 0.) {
+    if (any_l && method <= 3 && (rc = ddrl_pop_update_best_param(h->pop, score.data(), lm.data()))) return rc;
+    if (any_l && (rc = ddrl_pop_ewc_decay_update(h->pop, lm.data()))) return rc;
+    if (any_t && method >= 4 && (rc = ddrl_pop_update_best_param(h->pop, score.data(), tm.data()))) return rc;
+  }
+  for (int g = 0; g < G; ++g) if (lm[g]) h->ag[g].episode++;
+  return ddrl_pop_sync(h->pop);
+}
+
+extern "C" int ddrl_agents_stats(ddrl_agents_t *h, double *sum_weighted_reward, double *sum_reward, int32_t *episode) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  for (int g = 0; g < h->G; ++g) {
+    if (sum_weighted_reward) sum_weighted_reward[g] = h->ag[g].sum_weighted_reward;
+    if (sum_reward) sum_reward[g] = h->ag[g].sum_reward;
+    if (episode) episode[g] = h->ag[g].episode;
+  }
+  return DDRL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// G = 1 C flavour: the reference's names and argument types (ddpg.cpp:9-88; gym/agent.py:113-118)
+// ---------------------------------------------------------------------------------------------
+struct DDPGAgShim {
+  unsigned nb_motors, nb_sensors;
+  ddrl_agents *ag = nullptr;
+};
+
+extern "C" int64_t DDPGAg_new(unsigned nb_motors, unsigned nb_sensors) {
+  DDPGAgShim *s = new DDPGAgShim();
+  s->nb_motors = nb_motors;
+  s->nb_sensors = nb_sensors;
+  return (int64_t)(intptr_t)s;
+}
+
+// argv: "--config <file>" (default config.ini, ddpg.cpp:22,35-37); unknown options are ignored like
+// allow_unregistered().  The library never exits: failures are reported on stderr and leave the
+// agent unconfigured (every later call is then a no-op returning NULL / nothing).
+extern "C" void DDPGAg_unique_invoke(int64_t hnd, int argc, char **argv) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (!s) return;
+  std::string config = "config.ini";
+  uint64_t seed = std::random_device{}();
+  for (int i = 0; i < argc; ++i) {
+    if (!argv[i]) continue;
+    const std::string a(argv[i]);
+    if (a == "--config" && i + 1 < argc && argv[i + 1]) config = argv[++i];
+    else if (a.rfind("--config=", 0) == 0) config = a.substr(9);
+    else if (a == "--seed" && i + 1 < argc && argv[i + 1]) seed = strtoull(argv[++i], nullptr, 10);
+  }
+  if (ddrl_agents_create_ddpg(config.c_str(), 1, (int)s->nb_sensors, (int)s->nb_motors, -1, seed, &s->ag) != DDRL_OK)
+    fprintf(stderr, "DDPGAg_unique_invoke: %s\n", ddrl_last_error());
+}
+
+extern "C" void DDPGAg_start_episode(int64_t hnd, const double *state, bool learning) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (!s || !s->ag || !state) return;
+  std::vector<float> st(state, state + s->nb_sensors);
+  const uint8_t l = learning;
+  if (ddrl_agents_start_episode(s->ag, st.data(), &l, nullptr) != DDRL_OK) fprintf(stderr, "DDPGAg_start_episode: %s\n", ddrl_last_error());
+}
+
+extern "C" const double *DDPGAg_run(int64_t hnd, double reward, const double *sensors, bool learning, bool goal_reached, bool last) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (!s || !s->ag || !sensors) return nullptr;
+  std::vector<float> st(sensors, sensors + s->nb_sensors), act(s->nb_motors);
+  const float r = (float)reward;
+  const uint8_t l = learning, g = goal_reached, e = last;
+  if (ddrl_agents_run(s->ag, &r, st.data(), &l, &g, &e, nullptr, act.data()) != DDRL_OK) {
+    fprintf(stderr, "DDPGAg_run: %s\n", ddrl_last_error());
+    return nullptr;
+  }
+  for (unsigned i = 0; i < s->nb_motors; ++i) s->ag->ret_double[i] = act[i];
+  return s->ag->ret_double.data();
+}
+
+extern "C" void DDPGAg_end_episode(int64_t hnd, bool learning) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (!s || !s->ag) return;
+  const uint8_t l = learning;
+  if (ddrl_agents_end_episode(s->ag, &l, nullptr) != DDRL_OK) fprintf(stderr, "DDPGAg_end_episode: %s\n", ddrl_last_error());
+}
+
+// the reference appends "<episode> <step> <treward> <agent dump>" to 0.learning.data / 0.testing.data
+// (ddpg.cpp:64-68); the agent dump fields are specific to its Caffe wrapper, only the prefix is kept
+extern "C" void DDPGAg_dump(int64_t hnd, bool learning, int episode, int step, double treward) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (!s || !s->ag) return;
+  FILE *f = fopen(learning ? "0.learning.data" : "0.testing.data", "a");
+  if (!f) return;
+  fprintf(f, "%d %d %f %f\n", episode, step, treward, s->ag->ag[0].sum_weighted_reward);
+  fclose(f);
+}
+
+extern "C" void DDPGAg_display(int64_t hnd, bool learning, int episode, int step, double treward) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (!s || !s->ag) return;
+  printf("%s %-6d%-7d%-7f %f\n", learning ? "L" : "T", episode, step, treward, s->ag->ag[0].sum_weighted_reward);
+}
+
+// weights of the four nets, flat reference order, as raw doubles: agent<episode>.ddrl_pop
+static int save_load(DDPGAgShim *s, int episode, bool save) {
+  const std::string path = "agent" + std::to_string(episode) + ".ddrl_pop";
+  FILE *f = fopen(path.c_str(), save ? "wb" : "rb");
+  if (!f) return ddrl_fail(DDRL_EIO, "cannot open %s", path.c_str());
+  int rc = DDRL_OK;
+  for (int net = 0; net < 4 && rc == DDRL_OK; ++net) {
+    const int n = ddrl_pop_num_params(s->ag->pop, net);
+    std::vector<double> w(n);
+    if (save) {
+      rc = ddrl_pop_get_weights(s->ag->pop, net, w.data());
+      if (rc == DDRL_OK && fwrite(w.data(), sizeof(double), n, f) != (size_t)n) rc = ddrl_fail(DDRL_EIO, "short write to %s", path.c_str());
+    } else {
+      if (fread(w.data(), sizeof(double), n, f) != (size_t)n) rc = ddrl_fail(DDRL_EIO, "%s does not match this agent's nets", path.c_str());
+      else rc = ddrl_pop_set_weights(s->ag->pop, net, w.data());
+    }
+  }
+  fclose(f);
+  return rc;
+}
+
+extern "C" void DDPGAg_save(int64_t hnd, int episode) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (s && s->ag && save_load(s, episode, true) != DDRL_OK) fprintf(stderr, "DDPGAg_save: %s\n", ddrl_last_error());
+}
+
+extern "C" void DDPGAg_load(int64_t hnd, int episode) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (s && s->ag && save_load(s, episode, false) != DDRL_OK) fprintf(stderr, "DDPGAg_load: %s\n", ddrl_last_error());
+}
+
+// not in the reference's binding (it leaks the agent); provided so that callers can release the GPU
+extern "C" void DDPGAg_delete(int64_t hnd) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)hnd;
+  if (!s) return;
+  ddrl_agents_destroy(s->ag);
+  delete s;
+}

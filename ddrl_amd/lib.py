@@ -85,6 +85,23 @@ SYMBOLS = [
     ("ddrl_pop_profile_read", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     ("ddrl_pop_debug_stamps", _i, [_vp, _i, _vp]),
     ("ddrl_pop_set_option", _i, [_vp, _cp, _i]),
+    ("ddrl_agents_create_ddpg", _i, [_cp, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_agents_destroy", _i, [_vp]),
+    ("ddrl_agents_population", _vp, [_vp]),
+    ("ddrl_agents_start_episode", _i, [_vp, _vp, _vp, _vp]),
+    ("ddrl_agents_run", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_agents_end_episode", _i, [_vp, _vp, _vp]),
+    ("ddrl_agents_stats", _i, [_vp, _vp, _vp, _vp]),
+    ("DDPGAg_new", C.c_int64, [C.c_uint, C.c_uint]),
+    ("DDPGAg_unique_invoke", None, [C.c_int64, _i, C.POINTER(_cp)]),
+    ("DDPGAg_start_episode", None, [C.c_int64, _vp, C.c_bool]),
+    ("DDPGAg_run", _vp, [C.c_int64, C.c_double, _vp, C.c_bool, C.c_bool, C.c_bool]),
+    ("DDPGAg_end_episode", None, [C.c_int64, C.c_bool]),
+    ("DDPGAg_dump", None, [C.c_int64, C.c_bool, _i, _i, C.c_double]),
+    ("DDPGAg_display", None, [C.c_int64, C.c_bool, _i, _i, C.c_double]),
+    ("DDPGAg_save", None, [C.c_int64, _i]),
+    ("DDPGAg_load", None, [C.c_int64, _i]),
+    ("DDPGAg_delete", None, [C.c_int64]),
     ("ddrl_nfac_config_default", _i, [C.POINTER(NfacConfigC)]),
     ("ddrl_nfac_config_from_ini", _i, [_cp, C.POINTER(NfacConfigC)]),
     ("ddrl_nfac_create", _i, [C.POINTER(NfacConfigC), C.c_uint64, C.POINTER(_vp)]),

@@ -18,6 +18,7 @@
  */
 #ifndef DDRL_POP_H
 #define DDRL_POP_H
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -136,6 +137,51 @@ int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost /* [G] */);
 /* fisher, fisher_hat (previous_fisher), wstar (best_param_previous_task): [G x n_params] */
 int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat, double *wstar,
                      double *fisher_nbr /* [G] */, double *decay_mult /* [G] */);
+
+/* ------------------------------------------------------------------------------------------------
+ * Agent-level front end over a DDPG population: ARLAgent::runf / start_episode
+ * (common/include/arch/ARLAgent.hpp:37-137: decision_each, reward max-pooling, reward_scale,
+ * discounted-return bookkeeping) around DeepQNAg::_run / insertSample / end_episode / end_instance
+ * (agent/deepqn/include/DeepQNAg.hpp:122-165, 290-339), for G agents per call.  Exploration noise
+ * (agent.gaussian_policy 0 e-greedy / 1 truncated Gaussian / 2 Ornstein-Uhlenbeck, agent.noise*)
+ * runs on the host per agent (same distributions as the reference; its clock-seeded stream is not
+ * reproducible).  Every array is per agent; mask NULL = all agents.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ddrl_agents ddrl_agents_t;
+/* reads [agent] (+ [devnn]) of a reference .ini: the ddrl_ddpg_config keys plus agent.noise,
+ * gaussian_policy, decision_each, reward_scale, noise2, noise3 */
+int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int device,
+                            uint64_t seed, ddrl_agents_t **out);
+int ddrl_agents_destroy(ddrl_agents_t *h);
+/* the population underneath (weights, Adam state, EWC life-cycle); owned by the front end */
+ddrl_pop_t *ddrl_agents_population(ddrl_agents_t *h);
+int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states /* [G x S] */, const uint8_t *learning,
+                              const uint8_t *mask);
+/* one environment step: returns the action to apply [G x A].  On a decision step of a learning
+ * agent: store the transition, run 1 + force_more_update update passes (DeepQNAg.hpp:159-165,341),
+ * then perturb the policy's action. */
+int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const float *states, const uint8_t *learning,
+                    const uint8_t *goal, const uint8_t *last, const uint8_t *mask, float *actions_out);
+/* end_episode(learning) + end_instance(learning) as DDPGAg_end_episode does (ddpg.cpp:52-55) */
+int ddrl_agents_end_episode(ddrl_agents_t *h, const uint8_t *learning, const uint8_t *mask);
+int ddrl_agents_stats(ddrl_agents_t *h, double *sum_weighted_reward, double *sum_reward, int32_t *episode);
+
+/* The reference's own C flavour for one agent, same names and argument types
+ * (agent/deepqn/src/pybinding/ddpg.cpp:9-88; ctypes caller gym/agent.py:112-157): an existing
+ * driver can load libddrl_pop.so in place of libddrl-ddpg.so.  Handles are int64 as gym/agent.py
+ * declares them.  DDPGAg_unique_invoke understands "--config <ini>" (default config.ini) and, in
+ * addition, "--seed <n>".  DDPGAg_run returns a buffer of nb_motors doubles valid until the next
+ * call.  DDPGAg_delete has no counterpart (the reference's binding never frees the agent). */
+int64_t DDPGAg_new(unsigned nb_motors, unsigned nb_sensors);
+void DDPGAg_unique_invoke(int64_t ag, int argc, char **argv);
+void DDPGAg_start_episode(int64_t ag, const double *state, bool learning);
+const double *DDPGAg_run(int64_t ag, double reward, const double *sensors, bool learning, bool goal_reached, bool last);
+void DDPGAg_end_episode(int64_t ag, bool learning);
+void DDPGAg_dump(int64_t ag, bool learning, int episode, int step, double treward);
+void DDPGAg_display(int64_t ag, bool learning, int episode, int step, double treward);
+void DDPGAg_save(int64_t ag, int episode);
+void DDPGAg_load(int64_t ag, int episode);
+void DDPGAg_delete(int64_t ag);
 
 /* ------------------------------------------------------------------------------------------------
  * NFAC(lambda)-V (agent/cacla/include/OfflineCaclaAg.hpp): population of G independent agents,
