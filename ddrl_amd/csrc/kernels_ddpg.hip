@@ -18,6 +18,7 @@ struct LdsMap {
   float *xc, *xa;            // critic input [s|a] tile, actor input s tile
   float *topq, *topa;        // output tiles: q [64 x 4], actions [64 x ld(A)]
   float *yv, *rv, *dn;       // TD target, reward, goal flag per row
+  float *nrew; int *nvalid;  // n-step return: discounted reward prefix and horizon per row
 };
 
 // gather one 64-row tile of the minibatch from the agent's replay ring (DeepQNAg.hpp:353-377,
@@ -32,7 +33,7 @@ __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, i
     const int row = e / ldxc, col = e - row * ldxc;
     float v = 0.f;
     if (row < B) {
-      int phys = head + idx[row];
+      int phys = head + idx[row] + (next && P.nstep > 0 ? M.nvalid[row] : 0);   // s' of the last valid step (:361-372)
       if (phys >= P.cap) phys -= P.cap;
       const float *rr = rep + (size_t)phys * P.rowlen;
       if (next) { if (col < S) v = rr[S + A + col]; }
@@ -104,6 +105,8 @@ ddpg_update_kernel(const DdpgParams P) {
   M.yv = p; p += DDRL_MB;
   M.rv = p; p += DDRL_MB;
   M.dn = p; p += DDRL_MB;
+  M.nrew = p; p += DDRL_MB;
+  M.nvalid = (int *)p; p += DDRL_MB;
 
   long long *stamps = P.stamps ? P.stamps + (size_t)agent * 16 : nullptr;
 #define STAMP(i) do { if (stamps && tid == 0) stamps[i] = clock64(); } while (0)
@@ -112,6 +115,35 @@ ddpg_update_kernel(const DdpgParams P) {
   const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
   const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
   const float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
+
+  // ---- n-step horizon (DeepQNAg.hpp:360-373, 394-402): the horizon stops before a transition that
+  // reached the goal and at the end of the replay; rewards of steps [0, valid) are discounted ----
+  if (P.nstep > 0) {
+    if (tid < DDRL_MB) {
+      int valid = 0;
+      float acc = 0.f;
+      if (tid < B) {
+        const float *rep = P.rep + (size_t)agent * P.cap * P.rowlen;
+        const int i0 = idx[tid];
+        int last = i0;
+        for (int j = i0 + 1; j < i0 + P.nstep && j < len; ++j) {
+          const int ph = head + j >= P.cap ? head + j - P.cap : head + j;
+          if (rep[(size_t)ph * P.rowlen + 2 * S + A + 1] != 0.f) break;
+          last = j;
+        }
+        valid = last - i0;
+        float lg = 1.f;
+        for (int j = 0; j < valid; ++j) {
+          const int ph = head + i0 + j >= P.cap ? head + i0 + j - P.cap : head + i0 + j;
+          acc += rep[(size_t)ph * P.rowlen + 2 * S + A] * lg;
+          lg *= gamma;
+        }
+      }
+      M.nvalid[tid] = valid;
+      M.nrew[tid] = acc;
+    }
+    __syncthreads();
+  }
 
   // ---- a' = ann_target(s'), q' = qnn_target(s', a')  (DeepQNAg.hpp:379-383) ----
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, head, true, M, tid);
@@ -130,7 +162,8 @@ ddpg_update_kernel(const DdpgParams P) {
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, head, false, M, tid);
   if (tid < DDRL_MB) {
     const float qn = M.topq[tid * ldq];
-    M.yv[tid] = M.dn[tid] != 0.f ? M.rv[tid] : M.rv[tid] + gamma * qn;
+    // :388-403.  n-step: sum_{j<valid} gamma^j r_{t+j} + gamma * Q' (the reference's exponent, not gamma^valid)
+    M.yv[tid] = M.dn[tid] != 0.f ? M.rv[tid] : (P.nstep > 0 ? M.nrew[tid] : M.rv[tid]) + gamma * qn;
   }
   __syncthreads();
   if (P.qt_out && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];
@@ -206,7 +239,7 @@ ddpg_update_kernel(const DdpgParams P) {
 extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P) {
   size_t f = 0;
   { const int nh = (P->a.L_ > P->q.L_ ? P->a.L_ : P->q.L_) - 1; f += (size_t)nh * DDRL_MB * P->ldh; }
-  f += (size_t)DDRL_MB * (P->ldxc + P->ldxa + P->q.ld_[P->q.L_] + P->a.ld_[P->a.L_] + 3);
+  f += (size_t)DDRL_MB * (P->ldxc + P->ldxa + P->q.ld_[P->q.L_] + P->a.ld_[P->a.L_] + 5);
   return f * sizeof(float);
 }
 

@@ -100,7 +100,6 @@ static int validate(const ddrl_ddpg_config *c) {
   if (c->hidden_layer_type < 1 || c->hidden_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "hidden_layer_type not in (1,2,3)");
   if (c->actor_output_layer_type < 0 || c->actor_output_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "actor_output_layer_type not in 0..3");
   if (c->momentum < 0 || c->momentum > 3) return ddrl_fail(DDRL_EINVAL, "momentum not in 0..3");
-  if (c->nstep_return > 0) return ddrl_fail(DDRL_EINVAL, "nstep_return > 0 is not supported on the device path yet");
   if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
   if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
   return DDRL_OK;
@@ -191,6 +190,7 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   P.sa = h->net[0].st; P.sq = h->net[1].st;
   P.G = G; P.S = S; P.A = A; P.B = B; P.cap = cfg->replay_memory; P.rowlen = h->rowlen;
   P.inverting = cfg->inverting_grad ? 1 : 0;
+  P.nstep = cfg->nstep_return;
   P.ldxc = ddrl_ldpad(S + A); P.ldxa = ddrl_ldpad(S);
   P.ldh = 4;
   for (int k = 0; k < 2; ++k)

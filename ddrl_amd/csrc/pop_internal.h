@@ -109,6 +109,7 @@ struct DdpgParams {
   NetState sa, sq;
   int G, S, A, B, cap, rowlen;
   int inverting;
+  int nstep;                // agent.nstep_return (<= 0: one-step targets)
   int ldxc, ldxa;           // LDS strides of the critic / actor input tiles
   int ldh;                  // LDS row stride reserved for each hidden-activation buffer
   float beta1, beta2, omb1, omb2, eps;

@@ -59,7 +59,7 @@ typedef struct {
   int    hidden_layer_type;        /* 1 leaky-ReLU(0.01), 2 tanh, 3 ReLU (MLP.hpp:798-803) */
   int    actor_output_layer_type;  /* 0 linear, 1 leaky, 2 tanh, 3 ReLU (MLP.hpp:223-237) */
   int    momentum;                 /* 0..3 -> Adam betas (MLP.hpp:160-173) */
-  int    nstep_return;             /* agent.nstep_return; only 0 supported on device this round */
+  int    nstep_return;             /* agent.nstep_return (DeepQNAg.hpp:360-373, 394-402) */
   int    batch_norm_actor, batch_norm_critic;  /* must be 0 this round (BatchNorm out of scope) */
   double gamma;                    /* agent.gamma */
   double tau_soft_update, alpha_a, alpha_v, decay_v;

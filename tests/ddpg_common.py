@@ -4,27 +4,28 @@ import numpy as np
 NETS = ("ann", "qnn", "ann_target", "qnn_target")
 
 
-def synth_transitions(rng, n, S, A):
+def synth_transitions(rng, n, S, A, goal_prob=0.01):
     """s,s' ~ U(-1,1)^S, a ~ U(-1,1)^A, r ~ N(0,1), goal ~ Bernoulli(0.01)."""
     s = rng.uniform(-1, 1, (n, S)).astype(np.float32)
     a = rng.uniform(-1, 1, (n, A)).astype(np.float32)
     s2 = rng.uniform(-1, 1, (n, S)).astype(np.float32)
     r = rng.normal(0, 1, n).astype(np.float32)
-    goal = (rng.uniform(0, 1, n) < 0.01).astype(np.float32)
+    goal = (rng.uniform(0, 1, n) < goal_prob).astype(np.float32)
     return np.concatenate([s, a, s2, r[:, None], goal[:, None]], axis=1)
 
 
 def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100), n_replay=1000,
               replay_cap=2000, wscale=0.01, seed=0, hidden_act=1, actor_out_act=2, momentum=0,
               inverting_grad=True, decay_v=-1.0, sweep=True, ewc=-1.0, ewc_decay=-1.0,
-              ewc_fisher_beta=0.999, ewc_for_critic=0, ewc_best_method=0, force_generic=False):
+              ewc_fisher_beta=0.999, ewc_for_critic=0, ewc_best_method=0, force_generic=False, nstep_return=0,
+              goal_prob=0.01):
     import ddrl_amd
     rng = np.random.RandomState(seed)
     cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=B,
                               replay_memory=replay_cap, hidden_unit_a=hidden_a, hidden_unit_q=hidden_q,
                               hidden_layer_type=hidden_act, actor_output_layer_type=actor_out_act,
                               momentum=momentum, inverting_grad=int(inverting_grad), decay_v=decay_v,
-                              ewc=ewc, ewc_decay=ewc_decay, ewc_fisher_beta=ewc_fisher_beta,
+                              nstep_return=nstep_return, ewc=ewc, ewc_decay=ewc_decay, ewc_fisher_beta=ewc_fisher_beta,
                               ewc_for_critic=ewc_for_critic, ewc_best_param_method=ewc_best_method)
     pop = ddrl_amd.DdpgPopulation(cfg, init_seed=seed)
     pop.set_option("force_generic", int(force_generic))
@@ -47,13 +48,13 @@ def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100
     for g in range(G):
         ag = ora.Ddpg(S, A, B, hidden_a, hidden_q, replay_cap=replay_cap, hidden_act=hidden_act,
                       actor_out_act=actor_out_act, momentum=momentum, inverting_grad=inverting_grad,
-                      gamma=float(np.float32(gamma[g])), tau=float(np.float32(tau[g])),
+                      nstep_return=nstep_return, gamma=float(np.float32(gamma[g])), tau=float(np.float32(tau[g])),
                       alpha_a=float(np.float32(alpha_a[g])), alpha_v=float(np.float32(alpha_v[g])),
                       decay_v=decay_v, ewc=ewc, ewc_decay=ewc_decay, ewc_fisher_beta=ewc_fisher_beta,
                       ewc_for_critic=ewc_for_critic, ewc_best_method=ewc_best_method, seed=int(seeds[g]))
         ag.ann.set_weights(wa[g]); ag.ann_target.set_weights(wa[g])
         ag.qnn.set_weights(wq[g]); ag.qnn_target.set_weights(wq[g])
-        rows = synth_transitions(np.random.RandomState(1000 + g + 97 * seed), n_replay, S, A)
+        rows = synth_transitions(np.random.RandomState(1000 + g + 97 * seed), n_replay, S, A, goal_prob)
         pop.replay_load(g, rows)
         for row in rows.astype(np.float64):
             ag.insert(row[:S], row[S:S + A], row[2 * S + A], row[S + A:2 * S + A], row[2 * S + A + 1] != 0)

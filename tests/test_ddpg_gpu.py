@@ -65,6 +65,28 @@ def test_one_update_matches_oracle(ora, hidden_a, hidden_q, wscale, sweep, gener
     check_step(pop, agents, ws_prev, _hyper(agents), 0, TOL)
 
 
+@pytest.mark.parametrize("nstep,generic", [(1, False), (3, False), (5, True)])
+def test_nstep_return_targets(ora, nstep, generic):
+    """agent.nstep_return > 0 (DeepQNAg.hpp:360-373, 394-402): horizon cut at goal transitions and at
+    the end of the replay (indices near the end are forced into the batch), reference's exponent quirks."""
+    G = 3
+    pop, agents = make_pair(ora, G=G, hidden_a=(100, 100), hidden_q=(100, 100), wscale=0.1, nstep_return=nstep,
+                            goal_prob=0.15, force_generic=generic, seed=4)
+    ws_prev = [pop.weights(n) for n in range(4)]
+    rng = np.random.RandomState(9)
+    idx = rng.randint(0, 1000, (G, 64)).astype(np.int32)
+    idx[:, :6] = [999, 998, 997, 996, 0, 1]
+    pop.update(idx)
+    last = pop.last()
+    for g, ag in enumerate(agents):
+        loss, used = ag.update(idx[g])
+        qt, dact = ag.last()
+        assert rel_err(last["q_targets"][g], qt) <= TOL
+        assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+        assert rel_err(last["dact"][g], dact) <= TOL
+    check_step(pop, agents, ws_prev, _hyper(agents), 0, TOL)
+
+
 # momentum=3 (beta1=0.9, beta2=0: step = lr * m / |g|, unbounded as g -> 0, MLP.hpp:170-173) makes the
 # weights grow by orders of magnitude within a few updates in the reference arithmetic itself; it is
 # held to the bar for its first update only.
