@@ -38,6 +38,9 @@ __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, i
       const float *rr = rep + (size_t)phys * P.rowlen;
       if (next) { if (col < S) v = rr[S + A + col]; }
       else if (col < S + A) v = rr[col];
+      // developmental gates on the state inputs of both nets and on the critic's action input
+      if (P.sgate && col < S) v *= P.sgate[(size_t)agent * S + col];
+      if (P.agate && col >= S && col < S + A) v *= P.agate[(size_t)agent * A + col - S];
     }
     M.xc[e] = v;
     if (col < ldxa) M.xa[row * ldxa + col] = col < S ? v : 0.f;
@@ -113,6 +116,7 @@ ddpg_update_kernel(const DdpgParams P) {
   STAMP(0);
   const int *idx = P.idx + (size_t)agent * B;
   const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
+  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
   const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
   const float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
 
@@ -151,7 +155,13 @@ ddpg_update_kernel(const DdpgParams P) {
   fwd_net(na, na.L(), w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);
   for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
     const int row = e / A, col = e - row * A;
-    M.xc[row * ldxc + S + col] = M.topa[row * lda + col];
+    float a = M.topa[row * lda + col];
+    if (agate) {                       // the actor's output gate, then the critic's action-input gate
+      a *= agate[col];
+      M.topa[row * lda + col] = a;
+      a *= agate[col];
+    }
+    M.xc[row * ldxc + S + col] = a;
   }
   __syncthreads();
   STAMP(1);
@@ -192,7 +202,13 @@ ddpg_update_kernel(const DdpgParams P) {
   fwd_net(na, na.L(), w_a, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);       // pi = ann(s)
   for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
     const int row = e / A, col = e - row * A;
-    M.xc[row * ldxc + S + col] = M.topa[row * lda + col];
+    float a = M.topa[row * lda + col];
+    if (agate) {                       // the actor's output gate, then the critic's action-input gate
+      a *= agate[col];
+      M.topa[row * lda + col] = a;
+      a *= agate[col];
+    }
+    M.xc[row * ldxc + S + col] = a;
   }
   __syncthreads();
   STAMP(6);
@@ -206,12 +222,16 @@ ddpg_update_kernel(const DdpgParams P) {
     const int inverting = P.inverting, out_act = na.out_act();
     float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
     auto store = [=](int row, int h, float diff) {
-      const float out = topa[row * lda + h];
+      float out = topa[row * lda + h];
+      const float gt = agate ? agate[h] : 1.f;
+      diff *= gt;                                                        // the critic's action-input gate
       if (inverting) {                                                   // :432-450
         if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
         else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
       }
       if (dact_out && row < B) dact_out[row * A + h] = diff;
+      diff *= gt;                                                        // the actor's output gate
+      if (gt != 0.f) out /= gt;                                          // its activation saw the ungated value
       topa[row * lda + h] = act_bwd(out_act, out, diff);                 // actor's output layer, in place
     };
     OptCtx unused = {};

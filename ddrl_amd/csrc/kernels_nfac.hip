@@ -30,10 +30,12 @@ static size_t nfac_lds_bytes(const NetDesc &nd, int ldh) {
 
 // 64 rows [row0, row0 + 64) of the state columns starting at `col0` of the trajectory into Xs
 __device__ __forceinline__ void load_states(const float *__restrict__ traj, int rowlen, int T, int row0, int col0,
-                                            int S, int ldx, float *Xs, int tid) {
+                                            int S, int ldx, const float *__restrict__ sgate, float *Xs, int tid) {
   for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
     const int row = e / ldx, col = e - row * ldx;
-    Xs[e] = (row0 + row < T && col < S) ? traj[(size_t)(row0 + row) * rowlen + col0 + col] : 0.f;
+    float v = (row0 + row < T && col < S) ? traj[(size_t)(row0 + row) * rowlen + col0 + col] : 0.f;
+    if (sgate && col < S) v *= sgate[col];           // developmental state gate (shared by actor and critic)
+    Xs[e] = v;
   }
 }
 
@@ -54,7 +56,8 @@ nfac_values_kernel(const NfacParams P) {
   const float *w = P.sv.w + (size_t)agent * nv.stride();
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
-    load_states(traj, P.rowlen, T, row0, pass == 0 ? 0 : P.S + 2 * P.A, P.S, ldx, M.x, tid);
+    load_states(traj, P.rowlen, T, row0, pass == 0 ? 0 : P.S + 2 * P.A, P.S, ldx,
+                P.sgate ? P.sgate + (size_t)agent * P.S : nullptr, M.x, tid);
     __syncthreads();
     fwd_net(nv, nv.L(), w, M.x, ldx, M.hbase, M.hstride, M.top, ldt, wave, lane);
     float *out = (pass == 0 ? P.V : P.nextV) + (size_t)agent * P.maxT;
@@ -144,7 +147,7 @@ nfac_grad_kernel(const NfacParams P) {
   const size_t ro = (size_t)agent * P.maxT;
   const float *traj = P.traj + ro * P.rowlen;
   const float *w = st.w + (size_t)agent * nd.stride();
-  load_states(traj, P.rowlen, T, row0, 0, P.S, ldx, M.x, tid);
+  load_states(traj, P.rowlen, T, row0, 0, P.S, ldx, P.sgate ? P.sgate + (size_t)agent * P.S : nullptr, M.x, tid);
   __syncthreads();
   fwd_net(nd, nd.L(), w, M.x, ldx, M.hbase, M.hstride, M.top, ldt, wave, lane);
   if (MODE == 0) {
@@ -160,7 +163,9 @@ nfac_grad_kernel(const NfacParams P) {
     const int A = P.A;
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, h = e - row * A, li = row0 + row;
-      const float out = M.top[row * ldt + h];
+      const float gt = P.agate ? P.agate[(size_t)agent * A + h] : 1.f;
+      const float raw = M.top[row * ldt + h];
+      const float out = raw * gt;                                      // the actor's output gate
       float diff = 0.f;
       const int mode = li < T ? P.rowmode[ro + li] : 0;
       if (mode) {
@@ -171,7 +176,7 @@ nfac_grad_kernel(const NfacParams P) {
           else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
         }
       }
-      M.top[row * ldt + h] = act_bwd(nd.out_act(), out, diff);     // the actor's output layer, in place
+      M.top[row * ldt + h] = act_bwd(nd.out_act(), raw, diff * gt);   // the actor's output layer, in place
     }
   }
   __syncthreads();

@@ -323,6 +323,8 @@ extern "C" int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask) {
   HIPCHK(hipMemcpyAsync(n->d_endflag, flags.data(), flags.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(n->d_len, n->h_len.data(), G * sizeof(int), hipMemcpyHostToDevice, h->stream));
   n->P.mask = dmask;
+  n->P.sgate = h->gates_on ? h->d_sgate : nullptr;
+  n->P.agate = h->gates_on ? h->d_agate : nullptr;
   n->P.sa = h->net[0].st;
   n->P.sv = h->net[1].st;
   const int chunks = (maxlen + DDRL_MB - 1) / DDRL_MB;

@@ -370,7 +370,8 @@ extern "C" int ddrl_pop_infer_dev(ddrl_pop_t *h, const float *d_states, float *d
   if (!h || !d_states || !d_actions) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   int rc = set_device(h);
   if (rc) return rc;
-  HIPCHK(infer_launch(&h->net[0].nd, h->net[0].st.w, d_states, d_actions, nullptr, nullptr, h->G, h->stream));
+  HIPCHK(infer_launch(&h->net[0].nd, h->net[0].st.w, d_states, d_actions, h->gates_on ? h->d_sgate : nullptr,
+                      h->gates_on ? h->d_agate : nullptr, h->G, h->stream));
   return DDRL_OK;
 }
 
@@ -408,6 +409,8 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
                             h->net[0].d_lr, h->net[1].d_lr, h->net[0].st.iter, h->net[1].st.iter,
                             h->net[0].st.lr_t, h->net[1].st.lr_t, h->stream));
   h->P.mask = dmask;
+  h->P.sgate = h->gates_on ? h->d_sgate : nullptr;
+  h->P.agate = h->gates_on ? h->d_agate : nullptr;
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -438,6 +441,29 @@ extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, floa
   if (qt) HIPCHK(hipMemcpyAsync(qt, h->d_qt, G * B * 4, hipMemcpyDeviceToHost, h->stream));
   if (dact) HIPCHK(hipMemcpyAsync(dact, h->d_dact, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+// Developmental gates (DODevMLP.hpp:376-400; semantics SURVEY.md 8h): multiplicative per-dimension
+// gates on the state inputs of every net, on the actor's outputs and on the critic's action inputs,
+// shared by all nets of an agent; not learned (heuristic != 0: lr_mult = 0).  NULL, NULL switches
+// them off.  The schedule (DODevMLP::inform) is the caller's.
+extern "C" int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const double *action_gate) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  if (!state_gate && !action_gate) { h->gates_on = false; return DDRL_OK; }
+  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
+  if (!h->d_sgate) {
+    if ((rc = dalloc(h, &h->d_sgate, G * S))) return rc;
+    if ((rc = dalloc(h, &h->d_agate, G * A))) return rc;
+  }
+  std::vector<float> sg(G * S, 1.f), ag(G * A, 1.f);
+  if (state_gate) for (size_t i = 0; i < G * S; ++i) sg[i] = (float)state_gate[i];
+  if (action_gate) for (size_t i = 0; i < G * A; ++i) ag[i] = (float)action_gate[i];
+  if ((rc = upload_vec(h, h->d_sgate, sg))) return rc;
+  if ((rc = upload_vec(h, h->d_agate, ag))) return rc;
+  h->gates_on = true;
   return DDRL_OK;
 }
 

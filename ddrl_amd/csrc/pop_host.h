@@ -48,6 +48,9 @@ struct ddrl_pop {
   uint32_t *d_mt = nullptr;
   int *d_mtpos = nullptr;
   int *d_idx = nullptr;
+  // developmental gates (null until ddrl_pop_set_gates)
+  float *d_sgate = nullptr, *d_agate = nullptr;
+  bool gates_on = false;
   // hyper
   float *d_tau = nullptr, *d_omtau = nullptr, *d_gamma = nullptr;
   // diagnostics

@@ -119,6 +119,7 @@ struct DdpgParams {
   const int *idx;           // [G x B]
   const float *tau, *omtau, *gamma;   // [G]
   const uint8_t *mask;      // [G] or null
+  const float *sgate, *agate;   // developmental gates [G x S], [G x A] (DODevMLP.hpp:376-400), or null
   float *loss_out;          // [G]
   float *qt_out;            // [G x B] or null
   float *dact_out;          // [G x B x A] or null
@@ -139,6 +140,7 @@ struct NfacParams {
   const int *len;                 // [G]
   const uint8_t *endflag;         // [G x maxT] row is the last transition of its episode
   const float *gamma;             // [G]
+  const float *sgate, *agate;     // developmental gates [G x S], [G x A], or null
   const uint8_t *mask;            // [G] or null
   float *V, *nextV, *tgt, *deltas;   // [G x maxT]
   uint8_t *rowmode;               // [G x maxT] 0: no gradient, 1: target = a, 2: target = pure_a

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("ddrl_pop_infer_dev", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ddpg_update", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ddpg_last", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_pop_set_gates", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_update_best_param", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ewc_setup", _i, [_vp, _vp]),
     ("ddrl_pop_ewc_decay_update", _i, [_vp, _vp]),

@@ -104,6 +104,12 @@ class Population:
         _l.check(self.L.ddrl_pop_infer(self.h, _p(s), _p(out)))
         return out
 
+    # developmental gates of DODevMLP (state gate [G x S], action gate [G x A]); None, None = off
+    def set_gates(self, state_gate=None, action_gate=None):
+        sg = None if state_gate is None else np.ascontiguousarray(state_gate, np.float64).reshape(self.G, self.S)
+        ag = None if action_gate is None else np.ascontiguousarray(action_gate, np.float64).reshape(self.G, self.A)
+        _l.check(self.L.ddrl_pop_set_gates(self.h, _p(sg), _p(ag)))
+
     def update_best_param(self, score, mask=None):
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(score, np.float64), (self.G,)))
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

@@ -129,6 +129,14 @@ int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask)
  * action gradients fed to the actor [G x B x A].  Any pointer may be NULL. */
 int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *q_targets, float *dact);
 
+/* Developmental gates (DODevMLP.hpp:376-400 inserts the fork's "Developmental" layers; semantics as
+ * far as the tree pins them: SURVEY.md 8h): per agent, a multiplicative gate per state dimension
+ * (applied to the state input of every net) and per action dimension (applied to the actor's output
+ * and to the critic's action input), shared by the agent's nets, not learned (heuristic != 0).
+ * state_gate [G x S], action_gate [G x A]; either may be NULL (= ones); both NULL = gates off.  The
+ * schedule (DODevMLP::inform, :420-470) stays with the caller.  Applies to DDPG and NFAC handles. */
+int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const double *action_gate);
+
 /* EWC life-cycle (DODevMLP.hpp:604-758), per agent with mask[g] != 0 */
 int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score /* [G] */, const uint8_t *mask);
 int ddrl_pop_ewc_setup(ddrl_pop_t *h, const uint8_t *mask);
