@@ -79,6 +79,14 @@ class Cmaes:
         _l.check(self._L.ddrl_cmaes_get_vec(self._h, key.encode(), out.ctypes.data))
         return out.reshape(self.N, self.N) if key in ("C", "B") else out
 
+    def test_for_termination(self):
+        """'|'-separated names of the stopping criteria met ('' = keep going)"""
+        buf = C.create_string_buffer(256)
+        n = self._L.ddrl_cmaes_test_for_termination(self._h, buf, 256)
+        if n < 0:
+            _l.check(n)
+        return buf.value.decode()
+
     def index(self):
         idx = np.empty(self.lam, np.int32)
         _l.check(self._L.ddrl_cmaes_get_index(self._h, idx.ctypes.data))

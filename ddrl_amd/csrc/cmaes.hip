@@ -260,6 +260,9 @@ struct ddrl_cmaes {
   double gen = 0, countevals = 0, genOfEigensysUpdate = 0;
   int state = 0, eigen_uptodate = 1;
   std::vector<double> D, B;              // host copies (fp64): D [N], B [N x N]
+  // cmaes_TestForTermination inputs (cmaes.c:322-325, 347-349, 379-380, 817-836)
+  std::vector<double> hist, fitcur, init_stds;
+  double minEW = 0., maxEW = 0., dMaxSignifKond = 0., stopMaxFunEvals = 0., stopMaxIter = 0.;
   hipStream_t stream = nullptr;
   // device
   float *d_X = nullptr, *d_DZ = nullptr, *d_B = nullptr, *d_C = nullptr, *d_Y = nullptr;
@@ -468,6 +471,8 @@ static int update_eigensystem(ddrl_cmaes *h) {
     for (int j = 0; j <= i; ++j) Q[(size_t)i * N + j] = Q[(size_t)j * N + i] = (double)Cf[(size_t)i * h->ldn + j];
   eig::tridiag(N, Q, h->D.data(), e.data());
   eig::ql(N, h->D.data(), e.data(), Q);
+  h->minEW = *std::min_element(h->D.begin(), h->D.end());      // cmaes.c:1915-1916
+  h->maxEW = *std::max_element(h->D.begin(), h->D.end());
   for (int i = 0; i < N; ++i) h->D[i] = std::sqrt(h->D[i]);
   h->B = Q;
   h->eigen_uptodate = 1;
@@ -510,6 +515,8 @@ extern "C" int ddrl_cmaes_create(int N, const double *xstart, const double *stds
   h->ccov = t2;
   const double stopMaxFunEvals = 1 * 900 * (N + 3) * (N + 3);
   const double stopMaxIter = ceil((double)(stopMaxFunEvals / lambda));
+  h->stopMaxFunEvals = stopMaxFunEvals;
+  h->stopMaxIter = stopMaxIter;
   h->damps = 1 * (1 + 2 * std::max(0., sqrt((h->mueff - 1.) / (N + 1.)) - 1))
       * std::max(0.3, 1. - (double)N / (1e-6 + std::min(stopMaxIter, stopMaxFunEvals / lambda))) + h->cs;
   h->modulo = 1. / h->ccov / (double)(N) / 10.;
@@ -529,6 +536,16 @@ extern "C" int ddrl_cmaes_create(int N, const double *xstart, const double *stds
     h->D[i] = stds[i] * sqrt(N / trace);
     Cf[(size_t)i * h->ldn + i] = (float)(h->D[i] * h->D[i]);
   }
+  {
+    double dtest;
+    for (dtest = 1.; dtest && dtest < 1.1 * dtest; dtest *= 2.) if (dtest == dtest + 1.) break;
+    h->dMaxSignifKond = dtest / 1000.;
+  }
+  h->hist.assign(10 + (int)ceil(3. * 10. * N / lambda), 0.);
+  h->fitcur.assign(lambda, 0.);
+  h->init_stds.assign(stds, stds + N);
+  h->minEW = *std::min_element(h->D.begin(), h->D.end()); h->minEW *= h->minEW;
+  h->maxEW = *std::max_element(h->D.begin(), h->D.end()); h->maxEW *= h->maxEW;
   int rc;
   const size_t L = lambda, ldn = h->ldn;
   if ((rc = cm_alloc(h, &h->d_X, L * ldn))) return bail(rc);
@@ -681,6 +698,14 @@ extern "C" int ddrl_cmaes_update_dev(ddrl_cmaes_t *h, const double *d_fitness) {
     HIPCHK(hipMemcpyAsync(h->d_fit, d_fitness, h->lambda * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   int rc = rank_dev(h, h->d_fit, h->lambda, h->d_index);
   if (rc) return rc;
+  {  // rgFuncValue and the best-value history (cmaes.c:817-836), kept on the host for TestForTermination
+    int best = 0;
+    HIPCHK(hipMemcpyAsync(h->fitcur.data(), h->d_fit, h->lambda * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&best, h->d_index, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t i = h->hist.size() - 1; i > 0; --i) h->hist[i] = h->hist[i - 1];
+    h->hist[0] = h->fitcur[best];
+  }
   CmaesVecArgs a;
   a.N = N; a.ldx = h->ldn; a.ldn = h->ldn; a.lambda = h->lambda; a.mu = h->mu;
   a.mueff = h->mueff; a.cs = h->cs; a.damps = h->damps; a.ccumcov = h->ccumcov; a.chiN = h->chiN; a.gen = h->gen;
@@ -764,4 +789,58 @@ extern "C" int ddrl_cmaes_get_index(ddrl_cmaes_t *h, int32_t *index) {
   HIPCHK(hipMemcpyAsync(index, h->d_index, h->lambda * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return DDRL_OK;
+}
+
+// cmaes_TestForTermination (cmaes.c:1536-1667) with the defaults of cmaes_readpara_init (:2555-2559:
+// stopFitness off, stopTolFun 1e-12, stopTolFunHist 1e-13, stopTolX 0, stopTolUpXFactor 1e3).  CMAESAg
+// only logs the result (CMAESAg.hpp:145-154).  msg receives the '|'-separated names of the criteria
+// met; returns their number (0 = keep going) or a negative error code.
+extern "C" int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int msg_len) {
+  if (!h || (msg_len > 0 && !msg)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N;
+  std::vector<double> xmean(N), pc(N), diagC(N);
+  double sigma = 0.;
+  int rc;
+  if ((rc = ddrl_cmaes_get_vec(h, "xmean", xmean.data())) || (rc = ddrl_cmaes_get_vec(h, "pc", pc.data())) ||
+      (rc = ddrl_cmaes_get_vec(h, "diagC", diagC.data())) || (rc = ddrl_cmaes_get(h, "sigma", &sigma))) return rc;
+  std::string out;
+  int cnt = 0;
+  auto add = [&](const char *name) { if (cnt++) out += "|"; out += name; };
+  const double stopTolFun = 1e-12, stopTolFunHist = 1e-13, stopTolX = 0., stopTolUpXFactor = 1e3;
+  const int nhist = (int)h->hist.size();
+  const int nh = std::max(1, (int)std::min(h->gen, (double)nhist));     // rgdouMax over 0 elements reads element 0
+  double range = std::max(*std::max_element(h->hist.begin(), h->hist.begin() + nh), *std::max_element(h->fitcur.begin(), h->fitcur.end()))
+               - std::min(*std::min_element(h->hist.begin(), h->hist.begin() + nh), *std::min_element(h->fitcur.begin(), h->fitcur.end()));
+  if (h->gen > 0 && range <= stopTolFun) add("TolFun");
+  if (h->gen > nhist) {
+    range = *std::max_element(h->hist.begin(), h->hist.end()) - *std::min_element(h->hist.begin(), h->hist.end());
+    if (range <= stopTolFunHist) add("TolFunHist");
+  }
+  int cTemp = 0;
+  for (int i = 0; i < N; ++i) {
+    cTemp += (sigma * std::sqrt(diagC[i]) < stopTolX) ? 1 : 0;
+    cTemp += (sigma * pc[i] < stopTolX) ? 1 : 0;
+  }
+  if (cTemp == 2 * N) add("TolX");
+  for (int i = 0; i < N; ++i)
+    if (sigma * std::sqrt(diagC[i]) > stopTolUpXFactor * h->init_stds[i]) { add("TolUpX"); break; }
+  if (h->maxEW >= h->minEW * h->dMaxSignifKond) add("ConditionNumber");
+  if (!(0. >= h->gen)) {                                    // !flgdiag
+    for (int ax = 0; ax < N; ++ax) {
+      const double fac = 0.1 * sigma * h->D[ax];
+      int k = 0;
+      for (; k < N; ++k) if (xmean[k] != xmean[k] + fac * h->B[(size_t)k * N + ax]) break;
+      if (k == N) { add("NoEffectAxis"); break; }
+    }
+  }
+  for (int k = 0; k < N; ++k)
+    if (xmean[k] == xmean[k] + 0.2 * sigma * std::sqrt(diagC[k])) { add("NoEffectCoordinate"); break; }
+  if (h->countevals >= h->stopMaxFunEvals) add("MaxFunEvals");
+  if (h->gen >= h->stopMaxIter) add("MaxIter");
+  if (msg_len > 0) {
+    strncpy(msg, out.c_str(), msg_len - 1);
+    msg[msg_len - 1] = 0;
+  }
+  return cnt;
 }

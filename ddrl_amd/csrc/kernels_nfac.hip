@@ -313,3 +313,52 @@ extern "C" hipError_t nfac_finish_launch(const NfacParams *P, int critic_steps, 
   hipLaunchKernelGGL(nfac_finish_kernel, dim3((P->G + 255) / 256), dim3(256), 0, st, *P, critic_steps, actor_steps);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579) for every agent: n rows per agent through
+// one net.  X [G x n x d0], out [G x n x dL]; in_gate [G x d0] / out_gate [G x dL] or null.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DDRL_NTHREADS)
+net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out,
+                   int n, int ldh, const float *__restrict__ sgate, int S, const float *__restrict__ agate, int A,
+                   int gate_out) {
+  extern __shared__ __align__(16) float lds[];
+  const int chunk = blockIdx.x, agent = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = chunk * DDRL_MB;
+  const NfacLds M = nfac_carve(lds, nd, ldh);
+  const int d0 = nd.d(0), dl = nd.d(nd.L()), ldx = nd.ld(0), ldt = nd.ld(nd.L());
+  const float *xin = X + (size_t)agent * n * d0;
+  for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
+    const int row = e / ldx, col = e - row * ldx;
+    float v = (row0 + row < n && col < d0) ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
+    if (sgate && col < S) v *= sgate[(size_t)agent * S + col];
+    if (agate && !gate_out && col >= S && col < S + A) v *= agate[(size_t)agent * A + col - S];   // critic's action input
+    M.x[e] = v;
+  }
+  __syncthreads();
+  fwd_net(nd, nd.L(), w + (size_t)agent * nd.stride(), M.x, ldx, M.hbase, M.hstride, M.top, ldt, wave, lane);
+  float *o = out + (size_t)agent * n * dl;
+  for (int e = tid; e < DDRL_MB * dl; e += DDRL_NTHREADS) {
+    const int row = e / dl, col = e - row * dl;
+    if (row0 + row < n) {
+      float v = M.top[row * ldt + col];
+      if (agate && gate_out) v *= agate[(size_t)agent * A + col];                                  // actor's output
+      o[(size_t)(row0 + row) * dl + col] = v;
+    }
+  }
+}
+
+extern "C" hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
+                                         const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
+  static size_t conf = 0;
+  int ldh = 4;
+  for (int l = 1; l < nd->L_; ++l) ldh = std::max(ldh, nd->ld_[l]);
+  const size_t lds = nfac_lds_bytes(*nd, ldh);
+  hipError_t e = set_lds(net_forward_kernel, lds, conf);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(net_forward_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out,
+                     n, ldh, sgate, S, agate, A, gate_out);
+  return hipGetLastError();
+}

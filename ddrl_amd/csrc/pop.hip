@@ -16,6 +16,8 @@ hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap,
                                 const uint8_t *goal, const uint8_t *mask, hipStream_t st);
 hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, float *actions,
                         const float *in_gate, const float *out_gate, int G, hipStream_t st);
+hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
+                              const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
 hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st);
 hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat, float *nbr,
                             int stride, const uint8_t *flag, int G, hipStream_t st);
@@ -384,6 +386,29 @@ extern "C" int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions
   if ((rc = ddrl_pop_infer_dev(h, h->d_s, h->d_act))) return rc;
   HIPCHK(hipMemcpyAsync(actions, h->d_act, (size_t)G * A * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+// MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579): n rows per agent through one net
+extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float *x, float *out) {
+  if (!h || !x || !out || n < 1 || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const TrainNet *t = train_net(h, net);
+  const size_t G = h->G, d0 = t->nd.d(0), dl = t->nd.d(t->nd.L());
+  float *dx = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc(&dx, G * n * d0 * sizeof(float)));
+  if (hipMalloc(&dout, G * n * dl * sizeof(float)) != hipSuccess) { (void)hipFree(dx); return ddrl_fail(DDRL_ENOMEM, "hipMalloc failed"); }
+  const bool actor = net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET;
+  hipError_t e = hipMemcpyAsync(dx, x, G * n * d0 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess)
+    e = net_forward_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, h->gates_on ? h->d_sgate : nullptr, h->cfg.nb_sensors,
+                           h->gates_on ? h->d_agate : nullptr, h->cfg.nb_motors, actor ? 1 : 0, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, G * n * dl * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(dx);
+  (void)hipFree(dout);
+  if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "forward_batch: %s", hipGetErrorString(e));
   return DDRL_OK;
 }
 

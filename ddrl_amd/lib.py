@@ -74,6 +74,7 @@ SYMBOLS = [
     ("ddrl_pop_replay_len", _i, [_vp, _vp]),
     ("ddrl_pop_infer", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_infer_dev", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_forward_batch", _i, [_vp, _i, _i, _vp, _vp]),
     ("ddrl_pop_ddpg_update", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ddpg_last", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("ddrl_pop_set_gates", _i, [_vp, _vp, _vp]),
@@ -125,6 +126,7 @@ SYMBOLS = [
     ("ddrl_cmaes_get", _i, [_vp, _cp, C.POINTER(C.c_double)]),
     ("ddrl_cmaes_get_vec", _i, [_vp, _cp, _vp]),
     ("ddrl_cmaes_get_index", _i, [_vp, _vp]),
+    ("ddrl_cmaes_test_for_termination", _i, [_vp, _cp, _i]),
 ]
 
 _lib = None

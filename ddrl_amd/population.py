@@ -104,6 +104,16 @@ class Population:
         _l.check(self.L.ddrl_pop_infer(self.h, _p(s), _p(out)))
         return out
 
+    # MLP::computeOutBatch / computeOutVFBatch: x [G x n x in_dim] -> [G x n x out_dim]
+    def forward_batch(self, net, x):
+        x = np.ascontiguousarray(x, np.float32)
+        x = x.reshape(self.G, -1, x.shape[-1])
+        n = x.shape[1]
+        dl = {0: self.A, 2: self.A}.get(net, 1)
+        out = np.empty((self.G, n, dl), np.float32)
+        _l.check(self.L.ddrl_pop_forward_batch(self.h, net, n, _p(x), _p(out)))
+        return out
+
     # developmental gates of DODevMLP (state gate [G x S], action gate [G x A]); None, None = off
     def set_gates(self, state_gate=None, action_gate=None):
         sg = None if state_gate is None else np.ascontiguousarray(state_gate, np.float64).reshape(self.G, self.S)

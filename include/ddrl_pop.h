@@ -117,6 +117,12 @@ int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions);
 /* same with device-resident buffers (no PCIe in the loop) */
 int ddrl_pop_infer_dev(ddrl_pop_t *h, const float *d_states, float *d_actions);
 
+/* MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579) for all agents: n rows per agent through
+ * one net (any of the four; the critic's input rows are [s | a], an NFAC critic's are s).
+ * x [G x n x in_dim] -> out [G x n x out_dim], host buffers.  No ownership games: the reference
+ * returns a new std::vector the caller deletes (MLP.hpp:542,571). */
+int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float *x, float *out);
+
 /* One pass of the `fupd` loop body of DeepQNAg::end_episode (DeepQNAg.hpp:343-466) for every agent
  * with mask[g] != 0: sample B indices, gather, target forward passes, TD targets, critic Adam step,
  * deterministic policy gradient through the critic, inverting gradients, EWC terms, actor Adam
@@ -283,6 +289,11 @@ int ddrl_cmaes_rank(ddrl_cmaes_t *h, const double *fitness, int n, int32_t *inde
 int ddrl_cmaes_get(ddrl_cmaes_t *h, const char *key, double *out);
 int ddrl_cmaes_get_vec(ddrl_cmaes_t *h, const char *key, double *out);
 int ddrl_cmaes_get_index(ddrl_cmaes_t *h, int32_t *index /* [lambda] */);
+/* cmaes_TestForTermination (cmaes.c:1536-1667) with c-cmaes' default stopping parameters; CMAESAg
+ * only logs it (CMAESAg.hpp:145-154).  msg receives the '|'-separated names of the criteria met
+ * (TolFun, TolFunHist, TolX, TolUpX, ConditionNumber, NoEffectAxis, NoEffectCoordinate, MaxFunEvals,
+ * MaxIter); returns their number, 0 = keep going, < 0 = error. */
+int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int msg_len);
 
 /* Measurement hooks (no counterpart in the reference, which only records total wall minutes,
  * common/include/arch/Simulator.hpp:127): with profiling on, every ddrl_pop_ddpg_update() brackets

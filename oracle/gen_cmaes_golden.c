@@ -41,10 +41,25 @@ static void dump_ivec(const char *name, const int *v, int n, int last) {
   printf("]%s\n", last ? "" : ",");
 }
 
+static double f_const(const double *x, int n) { (void)x; (void)n; return 1.0; }
+
 typedef double (*fit_t)(const double *, int);
 
+/* names of the criteria cmaes_TestForTermination (cmaes.c:1536-1667) reports, '|'-separated */
+static void dump_term(cmaes_t *evo) {
+  static const char *names[] = {"Fitness:", "TolFun:", "TolFunHist:", "TolX:", "TolUpX:", "ConditionNumber:",
+                                "NoEffectAxis:", "NoEffectCoordinate:", "MaxFunEvals:", "MaxIter:"};
+  const char *msg = cmaes_TestForTermination(evo);
+  printf("    \"term\": \"");
+  int first = 1;
+  if (msg)
+    for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]); ++i)
+      if (strstr(msg, names[i])) { printf("%s%.*s", first ? "" : "|", (int)strlen(names[i]) - 1, names[i]); first = 0; }
+  printf("\",\n");
+}
+
 static void run_case(int N, int lambda, long seed, int gens, fit_t f, const char *fname, int full,
-                     double x0scale, double sigma0) {
+                     double x0scale, double sigma0, int term) {
   cmaes_t evo;
   double *x0 = (double *)malloc(sizeof(double) * N), *sd = (double *)malloc(sizeof(double) * N);
   for (int i = 0; i < N; ++i) { x0[i] = x0scale * (i + 1) / (double)N; sd[i] = sigma0; }
@@ -89,6 +104,7 @@ static void run_case(int N, int lambda, long seed, int gens, fit_t f, const char
       for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) printf("%s%.17g", (i || j) ? ", " : "", evo.C[i][j]);
       printf("],\n");
     }
+    if (term) dump_term(&evo);
     { double cs = 0; for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) cs += evo.C[i][j] * (1 + ((i + 2 * j) % 5));
       printf("    \"C_wsum\": %.17g\n", cs); }
     printf("   }%s\n", g + 1 < gens ? "," : "");
@@ -101,11 +117,14 @@ static void run_case(int N, int lambda, long seed, int gens, fit_t f, const char
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s <case>\n", argv[0]); return 2; }
   const char *c = argv[1];
-  if (!strcmp(c, "n5")) run_case(5, 8, 1, 20, f_sphere, "sphere", 1, 0.5, 0.5);
-  else if (!strcmp(c, "n12_ties")) run_case(12, 32, 7, 12, f_float_steps, "float_steps", 1, 1.0, 0.3);
-  else if (!strcmp(c, "n40")) run_case(40, 64, 3, 30, f_rosen, "rosen", 0, 0.2, 0.3);
-  else if (!strcmp(c, "n151")) run_case(151, 50, 2, 12, f_elli, "elli", 0, 0.1, 0.5);
-  else if (!strcmp(c, "n151_big")) run_case(151, 4096, 5, 3, f_sphere, "sphere", 0, 0.1, 0.5);
+  if (!strcmp(c, "n5")) run_case(5, 8, 1, 20, f_sphere, "sphere", 1, 0.5, 0.5, 0);
+  else if (!strcmp(c, "n12_ties")) run_case(12, 32, 7, 12, f_float_steps, "float_steps", 1, 1.0, 0.3, 0);
+  else if (!strcmp(c, "n40")) run_case(40, 64, 3, 30, f_rosen, "rosen", 0, 0.2, 0.3, 0);
+  else if (!strcmp(c, "n151")) run_case(151, 50, 2, 12, f_elli, "elli", 0, 0.1, 0.5, 0);
+  else if (!strcmp(c, "n151_big")) run_case(151, 4096, 5, 3, f_sphere, "sphere", 0, 0.1, 0.5, 0);
+  else if (!strcmp(c, "term_flat")) run_case(4, 6, 2, 30, f_const, "const", 1, 0.5, 0.5, 1);
+  else if (!strcmp(c, "term_noeffect")) run_case(4, 6, 4, 8, f_sphere, "sphere", 1, 144115188075855872.0 /* 2^57: means exactly representable in fp32 */, 1.0, 1);
+  else if (!strcmp(c, "term_sphere")) run_case(5, 8, 1, 20, f_sphere, "sphere", 1, 0.5, 0.5, 1);
   else if (!strcmp(c, "kat")) {
     /* SURVEY.md 8(c'): the known-answer vector (x0 = .1...5, sigma .5, seed 1, lambda 8) + tie rule
      * + the head of the gaussian stream */

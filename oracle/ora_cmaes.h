@@ -19,6 +19,7 @@ const double *ora_cmaes_ptr(const ora_cmaes *t, const char *key);
 const int *ora_cmaes_index(const ora_cmaes *t);
 /* test hook (teacher forcing: resync the oracle to the device's fp32-rounded state between steps) */
 void   ora_cmaes_set_sigma(ora_cmaes *t, double sigma);
+int    ora_cmaes_test_for_termination(const ora_cmaes *t, char *out /* >= 128 bytes */);
 #ifdef __cplusplus
 }
 #endif

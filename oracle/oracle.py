@@ -137,6 +137,7 @@ def lib():
     L.ora_cmaes_index.restype = C.POINTER(C.c_int)
     L.ora_cmaes_index.argtypes = [vp]
     L.ora_cmaes_set_sigma.argtypes = [vp, C.c_double]
+    L.ora_cmaes_test_for_termination.argtypes = [vp, C.c_char_p]
     _lib = L
     return L
 
@@ -403,6 +404,11 @@ class Cmaes:
         """writable view of the oracle's own array (teacher forcing in the GPU parity tests)"""
         n = self.N if n is None else n
         return np.ctypeslib.as_array(lib().ora_cmaes_ptr(self.h, key.encode()), shape=(n,))
+
+    def test_for_termination(self):
+        buf = C.create_string_buffer(256)
+        lib().ora_cmaes_test_for_termination(self.h, buf)
+        return buf.value.decode()
 
     def set_sigma(self, sigma):
         lib().ora_cmaes_set_sigma(self.h, float(sigma))

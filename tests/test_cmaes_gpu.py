@@ -68,7 +68,9 @@ def test_rank_tie_rule(ora):
     c.close()
 
 
-@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big"])
+# term_noeffect (|mean| ~ 1e17) is left to the CPU oracle test: with steps below one ulp of the mean the
+# update amplifies last-bit differences of the fp64 mean (FMA contraction) by 1e16; no fp32/fp64 bar applies.
+@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big", "term_flat", "term_sphere"])
 def test_generations_teacher_forced(ora, name):
     g = load(name)
     N, lam = g["N"], g["lambda"]
@@ -99,6 +101,9 @@ def test_generations_teacher_forced(ora, name):
         Cr = np.tril(Cr) + np.tril(Cr, -1).T          # c-cmaes maintains the lower triangle only
         assert nerr(Cd, Cr) <= TOL, gi
         assert np.array_equal(Cd, Cd.T), gi                                        # stays symmetric
+        # cmaes_TestForTermination: same criteria as the oracle stepping from the same state (the oracle
+        # itself reproduces the reference's strings on the golden runs, tests/test_oracle_cmaes.py)
+        assert dev.test_for_termination() == ref.test_for_termination(), gi
         # CMAESAg::getBestSolution's inputs (CMAESAg.hpp:328-335); X was synced, so exact
         assert dev.get("fbestever") == ref.get("fbestever"), gi
         assert np.array_equal(dev.vec("xbestever"), ref.vec("xbestever")), gi

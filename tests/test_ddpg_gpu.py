@@ -257,3 +257,17 @@ def test_ewc_lifecycle_matches_oracle(ora, hidden, for_critic):
             assert np.mean(np.abs(st["fisher"][g] - so["fisher"]) <= 1e-4 * np.max(so["fisher"])) >= 0.99
             assert abs(st["fisher_nbr"][g] - so["fisher_nbr"]) <= 1e-5 * so["fisher_nbr"]
             assert st["decay_mult"][g] == so["decay_mult"]
+
+
+def test_forward_batch_all_nets(ora):
+    """MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579): n rows per agent, n not a multiple of 64."""
+    G, S, A = 3, 18, 6
+    pop, agents = make_pair(ora, G=G, hidden_a=(64, 33), hidden_q=(100, 100), wscale=0.2, seed=3)
+    rng = np.random.RandomState(7)
+    for n in (1, 64, 150):
+        xs = rng.uniform(-1, 1, (G, n, S)).astype(np.float32)
+        xq = rng.uniform(-1, 1, (G, n, S + A)).astype(np.float32)
+        for net, x in ((0, xs), (1, xq), (2, xs), (3, xq)):
+            out = pop.forward_batch(net, x)
+            for g, ag in enumerate(agents):
+                assert rel_err(out[g], ag.nets[net].forward(x[g].astype(np.float64))) <= TOL, (n, net, g)

@@ -61,7 +61,7 @@ def test_survey_known_answer(ora):
     assert c.vec("ps")[0] == 0.13722626374428595 and c.vec("pc")[0] == 0.13699777064836419
 
 
-@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big"])
+@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big", "term_flat", "term_noeffect", "term_sphere"])
 def test_golden_runs(ora, name):
     g = load(name)
     N, lam = g["N"], g["lambda"]
@@ -88,6 +88,8 @@ def test_golden_runs(ora, name):
         assert list(np.diag(Cm)) == gen["diagC"], gi
         if "C_lower" in gen:
             assert list(Cm[np.tril_indices(N)]) == gen["C_lower"], gi
+        if "term" in gen:     # cmaes_TestForTermination's criteria (cmaes.c:1536-1667), by name
+            assert c.test_for_termination() == gen["term"], gi
 
 
 def test_ties_present_in_fixture():
