@@ -79,6 +79,9 @@ class Cmaes:
         _l.check(self._L.ddrl_cmaes_get_vec(self._h, key.encode(), out.ctypes.data))
         return out.reshape(self.N, self.N) if key in ("C", "B") else out
 
+    def set_option(self, key, value):
+        _l.check(self._L.ddrl_cmaes_set_option(self._h, key.encode(), int(value)))
+
     def test_for_termination(self):
         """'|'-separated names of the stopping criteria met ('' = keep going)"""
         buf = C.create_string_buffer(256)

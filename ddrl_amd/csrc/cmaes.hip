@@ -16,6 +16,8 @@
 #include "pop_internal.h"
 #include "host_util.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -235,6 +237,40 @@ __global__ void cmaes_pack_y(const float *__restrict__ X, int ldx, const int *__
   Y[(size_t)i * mu16 + k] = y;
 }
 
+// Throughput mode (ddrl_cmaes_set_option "device_rng"): D o z drawn on the device from a counter-based
+// generator (Philox4x32-10 + Box-Muller), one counter per 4 values, so rows can be produced in any
+// order on any rank.  NOT c-cmaes' stream: reproducible against itself only.
+__device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned int)p1; c[3] = (unsigned int)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ void cmaes_fill_dz_kernel(float *__restrict__ DZ, int ldn, const double *__restrict__ D, int rows, int N,
+                                     unsigned int seed, unsigned int draw, int row_base) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;      // 4 columns per thread
+  if (4 * q >= ldn || k >= rows) return;
+  unsigned int c[4] = {(unsigned int)q, (unsigned int)(row_base + k), draw, 0u};
+  philox4x32(c, seed, 0x5EEDu);
+  float z[4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float u1 = ((float)c[2 * p] + 1.0f) * 2.3283064e-10f;             // (0, 1]
+    const float u2 = (float)c[2 * p + 1] * 2.3283064e-10f;
+    const float r = sqrtf(-2.0f * logf(u1));
+    z[2 * p] = r * cospif(2.0f * u2);
+    z[2 * p + 1] = r * sinpif(2.0f * u2);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * q + e;
+    DZ[(size_t)k * ldn + i] = i < N ? (float)(D[i] * (double)z[e]) : 0.f;
+  }
+}
+
 // any |x_i| >= bound per individual (CMAESAg::is_feasible, CMAESAg.hpp:135-142)
 __global__ void cmaes_infeasible_kernel(const float *__restrict__ X, int ldx, int N, float bound, int *__restrict__ flag) {
   const int k = blockIdx.x;
@@ -259,6 +295,11 @@ struct ddrl_cmaes {
   // schedule
   double gen = 0, countevals = 0, genOfEigensysUpdate = 0;
   int state = 0, eigen_uptodate = 1;
+  int device_eigen = 0;                  // throughput mode: rocSOLVER dsyevd on the GPU instead of the host JAMA routines
+  double *d_A = nullptr, *d_ev = nullptr, *d_E = nullptr;
+  int *d_info = nullptr;
+  int device_rng = 0;                    // throughput mode: Philox on the device instead of c-cmaes' stream
+  unsigned int rng_seed = 0, rng_draw = 0;
   std::vector<double> D, B;              // host copies (fp64): D [N], B [N x N]
   // cmaes_TestForTermination inputs (cmaes.c:322-325, 347-349, 379-380, 817-836)
   std::vector<double> hist, fitcur, init_stds;
@@ -458,11 +499,82 @@ static int upload_BD(ddrl_cmaes *h) {
   return DDRL_OK;
 }
 
+// rocSOLVER / rocBLAS entry points, bound lazily: only the "device_eigen" throughput option needs them
+struct RocSolver {
+  void *blas = nullptr, *solver = nullptr, *handle = nullptr;
+  int (*create)(void **) = nullptr;
+  int (*set_stream)(void *, hipStream_t) = nullptr;
+  int (*dsyevd)(void *, int, int, int, double *, int, double *, double *, int *) = nullptr;
+};
+static RocSolver *rocsolver_get() {
+  static RocSolver rs;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    rs.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!rs.blas) rs.blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    rs.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!rs.solver) rs.solver = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (rs.blas && rs.solver) {
+      rs.create = (int (*)(void **))dlsym(rs.blas, "rocblas_create_handle");
+      rs.set_stream = (int (*)(void *, hipStream_t))dlsym(rs.blas, "rocblas_set_stream");
+      rs.dsyevd = (int (*)(void *, int, int, int, double *, int, double *, double *, int *))dlsym(rs.solver, "rocsolver_dsyevd");
+      if (rs.create && rs.set_stream && rs.dsyevd && rs.create(&rs.handle) != 0) rs.handle = nullptr;
+    }
+  }
+  return rs.handle ? &rs : nullptr;
+}
+
+// lower triangle of the fp32 C -> full fp64 matrix for the solver
+__global__ void cmaes_c_to_f64(const float *__restrict__ C, int ldn, int N, double *__restrict__ A) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= N || i >= N) return;
+  A[(size_t)i * N + j] = (double)(j <= i ? C[(size_t)i * ldn + j] : C[(size_t)j * ldn + i]);
+}
+
+static int upload_BD(ddrl_cmaes *h);
+
+// "device_eigen": C = B diag(D^2) B^T by rocsolver_dsyevd in fp64 on the GPU.  Any orthonormal
+// eigenbasis samples the same distribution; the basis differs from c-cmaes' Householder/QL one in
+// signs and inside (near-)degenerate eigenspaces, so this mode is for throughput, not for
+// seed-for-seed comparison.
+static int device_eigen(ddrl_cmaes *h) {
+  RocSolver *rs = rocsolver_get();
+  if (!rs) return ddrl_fail(DDRL_ESTATE, "device_eigen: librocsolver / librocblas could not be loaded");
+  const int N = h->N;
+  hipLaunchKernelGGL(cmaes_c_to_f64, dim3((N + 63) / 64, N), dim3(64), 0, h->stream, h->d_C, h->ldn, N, h->d_A);
+  HIPCHK(hipGetLastError());
+  if (rs->set_stream(rs->handle, h->stream) != 0) return ddrl_fail(DDRL_EHIP, "rocblas_set_stream failed");
+  // column-major lower == row-major upper of the same symmetric matrix: either triangle is complete here
+  if (rs->dsyevd(rs->handle, 211 /* rocblas_evect_original */, 122 /* rocblas_fill_lower */, N, h->d_A, N, h->d_ev, h->d_E, h->d_info) != 0)
+    return ddrl_fail(DDRL_EHIP, "rocsolver_dsyevd failed");
+  std::vector<double> A((size_t)N * N);
+  int info = 0;
+  HIPCHK(hipMemcpyAsync(A.data(), h->d_A, A.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->D.data(), h->d_ev, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (info != 0) return ddrl_fail(DDRL_EHIP, "rocsolver_dsyevd did not converge (info = %d)", info);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) h->B[(size_t)i * N + j] = A[(size_t)j * N + i];     // eigenvector j = column j (column-major)
+  return DDRL_OK;
+}
+
 // cmaes_UpdateEigensystem(t, 0) (cmaes.c:1885-1947) with the CPU-time gate off (maxtime = 1.0)
 static int update_eigensystem(ddrl_cmaes *h) {
   if (h->eigen_uptodate) return DDRL_OK;
   if (h->gen < h->genOfEigensysUpdate + h->modulo) return DDRL_OK;
   const int N = h->N;
+  if (h->device_eigen) {
+    int rc = device_eigen(h);
+    if (rc) return rc;
+    h->minEW = *std::min_element(h->D.begin(), h->D.end());
+    h->maxEW = *std::max_element(h->D.begin(), h->D.end());
+    for (int i = 0; i < N; ++i) h->D[i] = std::sqrt(std::max(h->D[i], 0.));
+    h->eigen_uptodate = 1;
+    h->genOfEigensysUpdate = h->gen;
+    return upload_BD(h);
+  }
   std::vector<float> Cf((size_t)N * h->ldn);
   HIPCHK(hipMemcpyAsync(Cf.data(), h->d_C, Cf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -521,6 +633,7 @@ extern "C" int ddrl_cmaes_create(int N, const double *xstart, const double *stds
       * std::max(0.3, 1. - (double)N / (1e-6 + std::min(stopMaxIter, stopMaxFunEvals / lambda))) + h->cs;
   h->modulo = 1. / h->ccov / (double)(N) / 10.;
   rnd_start(h, (unsigned long)seed);
+  h->rng_seed = (unsigned int)seed;
   // cmaes_init_final (cmaes.c:279-398)
   double trace = 0.;
   for (int i = 0; i < N; ++i) trace += stds[i] * stds[i];
@@ -590,10 +703,18 @@ extern "C" int ddrl_cmaes_destroy(ddrl_cmaes_t *h) {
 // rows [k0, k0 + n) of DZ <- D o z from the reference stream, then X rows = m + sigma * DZ * B^T
 static int sample_rows(ddrl_cmaes *h, int k0, int n) {
   const int N = h->N;
-  std::vector<float> dz((size_t)n * h->ldn, 0.f);
-  for (int k = 0; k < n; ++k)
-    for (int i = 0; i < N; ++i) dz[(size_t)k * h->ldn + i] = (float)(h->D[i] * rnd_gauss(h));   // cmaes.c:645
-  HIPCHK(hipMemcpyAsync(h->d_DZ + (size_t)k0 * h->ldn, dz.data(), dz.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  std::vector<float> dz;
+  if (h->device_rng) {
+    const dim3 grid((h->ldn / 4 + 63) / 64, n);
+    hipLaunchKernelGGL(cmaes_fill_dz_kernel, grid, dim3(64), 0, h->stream, h->d_DZ + (size_t)k0 * h->ldn, h->ldn, h->d_D, n, N,
+                       h->rng_seed, h->rng_draw++, k0);
+    HIPCHK(hipGetLastError());
+  } else {
+    dz.assign((size_t)n * h->ldn, 0.f);
+    for (int k = 0; k < n; ++k)
+      for (int i = 0; i < N; ++i) dz[(size_t)k * h->ldn + i] = (float)(h->D[i] * rnd_gauss(h));   // cmaes.c:645
+    HIPCHK(hipMemcpyAsync(h->d_DZ + (size_t)k0 * h->ldn, dz.data(), dz.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
   dim3 grid((N + 63) / 64, (n + 63) / 64);
   hipLaunchKernelGGL(cmaes_gemm_nt<0>, grid, dim3(256), 0, h->stream, h->d_DZ + (size_t)k0 * h->ldn, h->ldn, h->d_B, h->ldn,
                      h->d_X + (size_t)k0 * h->ldn, h->ldn, n, N, h->ldn, h->d_xmean, h->d_sc, 0., 0., 0., -1);
@@ -843,4 +964,24 @@ extern "C" int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int m
     msg[msg_len - 1] = 0;
   }
   return cnt;
+}
+
+// options (throughput modes; same algorithm, not seed-for-seed comparable with c-cmaes):
+//   "device_rng" (0/1): draw z on the device (Philox) instead of evaluating c-cmaes' sequential
+//   generator on the host;  "device_eigen" (0/1): eigendecomposition by rocSOLVER on the GPU.
+extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value) {
+  if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  if (std::string(key) == "device_rng") { h->device_rng = value != 0; return DDRL_OK; }
+  if (std::string(key) == "device_eigen") {
+    if (value && !h->d_A) {
+      HIPCHK(hipSetDevice(h->device));
+      int rc;
+      if ((rc = cm_alloc(h, &h->d_A, (size_t)h->N * h->N)) || (rc = cm_alloc(h, &h->d_ev, h->N)) ||
+          (rc = cm_alloc(h, &h->d_E, h->N)) || (rc = cm_alloc(h, &h->d_info, 1))) return rc;
+      if (!rocsolver_get()) return ddrl_fail(DDRL_ESTATE, "device_eigen: librocsolver / librocblas could not be loaded");
+    }
+    h->device_eigen = value != 0;
+    return DDRL_OK;
+  }
+  return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);
 }

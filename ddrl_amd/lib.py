@@ -127,6 +127,7 @@ SYMBOLS = [
     ("ddrl_cmaes_get_vec", _i, [_vp, _cp, _vp]),
     ("ddrl_cmaes_get_index", _i, [_vp, _vp]),
     ("ddrl_cmaes_test_for_termination", _i, [_vp, _cp, _i]),
+    ("ddrl_cmaes_set_option", _i, [_vp, _cp, _i]),
 ]
 
 _lib = None

@@ -294,6 +294,12 @@ int ddrl_cmaes_get_index(ddrl_cmaes_t *h, int32_t *index /* [lambda] */);
  * (TolFun, TolFunHist, TolX, TolUpX, ConditionNumber, NoEffectAxis, NoEffectCoordinate, MaxFunEvals,
  * MaxIter); returns their number, 0 = keep going, < 0 = error. */
 int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int msg_len);
+/* options: "device_rng" (0/1) -- throughput mode: z ~ N(0, I) is drawn on the GPU from a counter-based
+ * generator (Philox4x32-10) instead of c-cmaes' sequential LCG stream evaluated on the host
+ * (cmaes.c:2421-2482); "device_eigen" (0/1): the eigendecomposition (cmaes.c:1885-1947, O(N^3) on
+ * the host otherwise) by rocSOLVER dsyevd in fp64 on the GPU.  Same algorithm, different stream /
+ * eigenbasis: no counterpart in the reference. */
+int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value);
 
 /* Measurement hooks (no counterpart in the reference, which only records total wall minutes,
  * common/include/arch/Simulator.hpp:127): with profiling on, every ddrl_pop_ddpg_update() brackets

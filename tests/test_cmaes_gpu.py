@@ -166,3 +166,51 @@ def test_call_sequence_errors():
     with pytest.raises(DdrlError):
         Cmaes(np.zeros(4), np.ones(4), 0, 6)
     c.close()
+
+
+def test_device_rng_throughput_mode():
+    """"device_rng": z from Philox on the GPU -- not c-cmaes' stream; check the distribution, determinism
+    for a seed, and that rows do not repeat across calls."""
+    from ddrl_amd.cmaes import Cmaes
+    N, lam = 30, 2048
+    x0 = np.linspace(-1, 1, N)
+    a = Cmaes(x0, [0.5] * N, 11, lam); a.set_option("device_rng", 1)
+    b = Cmaes(x0, [0.5] * N, 11, lam); b.set_option("device_rng", 1)
+    c = Cmaes(x0, [0.5] * N, 12, lam); c.set_option("device_rng", 1)
+    Xa, Xb, Xc = a.sample(), b.sample(), c.sample()
+    assert np.array_equal(Xa, Xb) and not np.array_equal(Xa, Xc)
+    z = (Xa - x0) / 0.5                      # first generation: C = I, sigma = 0.5
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+    assert abs(np.mean(np.abs(z) > 1.96) - 0.05) < 0.005
+    assert np.max(np.abs(np.corrcoef(z.T) - np.eye(N))) < 0.12
+    a.update((Xa * Xa).sum(1))
+    X2 = a.sample()
+    assert not np.array_equal(X2[:5], Xa[:5])
+    a.resample(0)
+    assert not np.array_equal(a.population()[0], X2[0]) and np.array_equal(a.population()[1], X2[1])
+    for e in (a, b, c):
+        e.close()
+
+
+def test_device_eigen_throughput_mode():
+    """"device_eigen": rocSOLVER eigendecomposition on the GPU; the basis need not equal c-cmaes', but
+    it must be an orthonormal eigenbasis of the device's C, ascending, and the run must keep converging."""
+    from ddrl_amd.cmaes import Cmaes
+    N, lam = 40, 64
+    es = Cmaes(np.linspace(0.5, 1.5, N), [0.3] * N, 5, lam)
+    es.set_option("device_eigen", 1)
+    es.set_option("device_rng", 1)
+    f0 = None
+    for g in range(40):
+        X = es.sample()
+        if g > 0 and int(es.get("eigen_uptodate")) == 1:
+            B, D, Cm = es.vec("B"), es.vec("D"), C_prev
+            assert np.max(np.abs(B.T @ B - np.eye(N))) < 1e-5
+            assert np.all(np.diff(D) >= 0)
+            assert nerr(B @ np.diag(D * D) @ B.T, Cm) < 1e-5
+        f = ((X - 0.2) ** 2).sum(1)
+        f0 = f.min() if f0 is None else f0
+        es.update(f)
+        C_prev = es.vec("C")
+    assert f.min() < 0.2 * f0
+    es.close()
