@@ -7,4 +7,4 @@ it has no CPU path and raises if the library is missing.
 from .lib import load, LibraryMissing, DdrlError  # noqa: F401
 from .population import DdpgConfig, DdpgPopulation, NfacConfig, NfacPopulation  # noqa: F401
 from .cmaes import Cmaes  # noqa: F401
-from .agents import DdpgAgents, DDRLAg  # noqa: F401
+from .agents import DdpgAgents, NfacAgents, DDRLAg  # noqa: F401

@@ -1,11 +1,12 @@
-"""Python mirror of the agent-level front end (ddrl_agents_* and the reference's own DDPGAg_* names,
-include/ddrl_pop.h).  DDRLAg follows gym/agent.py:120-157 of the reference call for call."""
+"""Python mirror of the agent-level front end (ddrl_agents_* and the reference's own DDPGAg_* /
+OfflineCaclaAg_* names, include/ddrl_pop.h).  DDRLAg follows gym/agent.py:17-62 (NFAC) and :120-157
+(DDPG) of the reference call for call."""
 import ctypes as C
 
 import numpy as np
 
 from . import lib as _l
-from .population import Population, _p
+from .population import NfacPopulation, Population, _p
 
 
 class _Borrowed(Population):
@@ -20,15 +21,10 @@ class _Borrowed(Population):
     __del__ = close
 
 
-class DdpgAgents:
-    """G DDPG agents driven step by step: ARLAgent::runf + DeepQNAg::_run for every agent per call."""
-
-    def __init__(self, ini_path, n_agents, nb_sensors, nb_motors, seed=0, device=-1):
-        self.L = _l.load()
-        h = C.c_void_p()
-        _l.check(self.L.ddrl_agents_create_ddpg(ini_path.encode(), n_agents, nb_sensors, nb_motors, device, seed, C.byref(h)))
+class _Agents:
+    def _adopt(self, h, n_agents, nb_sensors, nb_motors):
         self.h, self.G, self.S, self.A = h, n_agents, nb_sensors, nb_motors
-        self.pop = _Borrowed(self.L, C.c_void_p(self.L.ddrl_agents_population(h)), n_agents, nb_sensors, nb_motors)
+        self.pop = self._view(self.L, C.c_void_p(self.L.ddrl_agents_population(h)), n_agents, nb_sensors, nb_motors)
 
     def close(self):
         if getattr(self, "h", None):
@@ -65,49 +61,85 @@ class DdpgAgents:
         return dict(sum_weighted_reward=swr, sum_reward=sr, episode=ep)
 
 
-class DDRLAg:
-    """gym/agent.py's DDRLAg against libddrl_pop.so: same methods, same DDPGAg_* calls."""
+class DdpgAgents(_Agents):
+    """G DDPG agents driven step by step: ARLAgent::runf + DeepQNAg::_run for every agent per call."""
+    _view = _Borrowed
 
-    def __init__(self, nb_motors, nb_sensors, argv=()):
+    def __init__(self, ini_path, n_agents, nb_sensors, nb_motors, seed=0, device=-1):
+        self.L = _l.load()
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_agents_create_ddpg(ini_path.encode(), n_agents, nb_sensors, nb_motors, device, seed, C.byref(h)))
+        self._adopt(h, n_agents, nb_sensors, nb_motors)
+
+
+class _BorrowedNfac(_Borrowed, NfacPopulation):
+    pass
+
+
+class NfacAgents(_Agents):
+    """G NFAC(lambda)-V agents: ARLAgent::runf + OfflineCaclaAg::_run / end_episode per call."""
+    _view = _BorrowedNfac
+
+    def __init__(self, ini_path, n_agents, nb_sensors, nb_motors, max_trajectory=0, seed=0, device=-1):
+        self.L = _l.load()
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_agents_create_nfac(ini_path.encode(), n_agents, nb_sensors, nb_motors, max_trajectory, device,
+                                                seed, C.byref(h)))
+        self._adopt(h, n_agents, nb_sensors, nb_motors)
+        self.pop.maxT = self.L.ddrl_nfac_max_trajectory(self.pop.h)
+        if self.pop.maxT < 0:
+            _l.check(self.pop.maxT)
+
+
+class DDRLAg:
+    """gym/agent.py's DDRLAg against libddrl_pop.so: same methods, same DDPGAg_* (algo="ddpg") or
+    OfflineCaclaAg_* (algo="nfac") calls."""
+
+    def __init__(self, nb_motors, nb_sensors, argv=(), algo="ddpg"):
         self.L = _l.load()
         self.nb_motors, self.nb_sensors = nb_motors, nb_sensors
-        self.obj = self.L.DDPGAg_new(nb_motors, nb_sensors)
+        self._pre = {"ddpg": "DDPGAg_", "nfac": "OfflineCaclaAg_"}[algo]
+        self._name = {"ddpg": "DDPG", "nfac": "NFAC(lambda)-V"}[algo]
+        self.obj = self._f("new")(nb_motors, nb_sensors)
         argv = list(argv) + [""]
         arr = (C.c_char_p * len(argv))(*[a.encode("utf-8") for a in argv])
-        self.L.DDPGAg_unique_invoke(self.obj, len(argv), arr)
+        self._f("unique_invoke")(self.obj, len(argv), arr)
+
+    def _f(self, name):
+        return getattr(self.L, self._pre + name)
 
     def run(self, reward, state, learning, goal, last):
         s = np.ascontiguousarray(state, np.float64)
-        p = self.L.DDPGAg_run(self.obj, reward, s.ctypes.data, learning, goal, last)
+        p = self._f("run")(self.obj, reward, s.ctypes.data, learning, goal, last)
         if not p:
             raise _l.DdrlError(-1, self.L.ddrl_last_error().decode(errors="replace"))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(self.nb_motors,)).copy()
 
     def start_ep(self, state, learning):
         s = np.ascontiguousarray(state, np.float64)
-        self.L.DDPGAg_start_episode(self.obj, s.ctypes.data, learning)
+        self._f("start_episode")(self.obj, s.ctypes.data, learning)
 
     def end_ep(self, learning):
-        self.L.DDPGAg_end_episode(self.obj, learning)
+        self._f("end_episode")(self.obj, learning)
 
     def dump(self, learning, episode, step, treward):
-        self.L.DDPGAg_dump(self.obj, learning, episode, step, treward)
+        self._f("dump")(self.obj, learning, episode, step, treward)
 
     def display(self, learning, episode, step, treward):
-        self.L.DDPGAg_display(self.obj, learning, episode, step, treward)
+        self._f("display")(self.obj, learning, episode, step, treward)
 
     def save(self, episode):
-        self.L.DDPGAg_save(self.obj, episode)
+        self._f("save")(self.obj, episode)
 
     def load(self, episode):
-        self.L.DDPGAg_load(self.obj, episode)
+        self._f("load")(self.obj, episode)
 
     def name(self):
-        return "DDPG"
+        return self._name
 
     def close(self):
         if getattr(self, "obj", None):
-            self.L.DDPGAg_delete(self.obj)
+            self._f("delete")(self.obj)
             self.obj = None
 
     __del__ = close

@@ -27,8 +27,10 @@ struct ddrl_agents {
   int G = 0, S = 0, A = 0;
   double gamma = 0.99, noise = 0., noise2 = 0., noise3 = 0., reward_scale = 1.;
   int gaussian_policy = 0, decision_each = 1, force_more_update = 0;
+  int algo = 0;                              // 0 DDPG (DeepQNAg), 1 NFAC (OfflineCaclaAg)
+  int update_each_episode = 1;
   std::vector<AgentState> ag;
-  std::vector<float> last_state, last_action, returned_ac, pure, rew;   // [G x S], [G x A], [G x A], [G x A], [G]
+  std::vector<float> last_state, last_action, last_pure, returned_ac, pure, rew;   // [G x S], [G x A] x 4, [G]
   std::vector<uint8_t> insert_mask, goal;
   std::vector<double> ret_double;            // DDPGAg_run's return buffer (valid until the next call)
 };
@@ -67,14 +69,21 @@ static double trunc_normal(std::mt19937 &eng, double a, double b, double mu, dou
 static void explore(ddrl_agents *h, int g, float *act) {
   AgentState &s = h->ag[g];
   const int A = h->A;
-  if (h->gaussian_policy == 1) {               // multidimentionnalTruncatedGaussian (MetropolisHasting.hpp:31-46)
+  std::uniform_real_distribution<double> U01(0., 1.);
+  // OfflineCaclaAg adds two schedules of the truncated Gaussian (OfflineCaclaAg.hpp:95-102)
+  int policy = h->gaussian_policy;
+  double sigma = h->noise;
+  if (h->algo == 1 && policy == 3) policy = U01(s.engine) < h->noise2 ? 1 : -1;
+  if (h->algo == 1 && policy == 4) { sigma = h->noise * std::pow(h->noise2, h->noise3 - (double)s.step); policy = 1; }
+  if (policy == -1) return;
+  if (policy == 1) {                           // multidimentionnalTruncatedGaussian (MetropolisHasting.hpp:31-46)
     for (int i = 0; i < A; ++i) {
       double mu = act[i];
-      if (mu > 1.0f + 3.f * h->noise) mu = 1.0f + 3.f * h->noise;
-      else if (mu < -1.0f - 3.f * h->noise) mu = -1.0f - 3.f * h->noise;
-      act[i] = (float)trunc_normal(s.engine, -1.0, 1.0, mu, h->noise);
+      if (mu > 1.0f + 3.f * sigma) mu = 1.0f + 3.f * sigma;
+      else if (mu < -1.0f - 3.f * sigma) mu = -1.0f - 3.f * sigma;
+      act[i] = (float)trunc_normal(s.engine, -1.0, 1.0, mu, sigma);
     }
-  } else if (h->gaussian_policy == 2) {        // OrnsteinUhlenbeckNoise::step (OrnsteinUhlenbeckNoise.hpp:22-37)
+  } else if (policy == 2) {                    // OrnsteinUhlenbeckNoise::step (OrnsteinUhlenbeckNoise.hpp:22-37)
     std::normal_distribution<double> dist(0., 1.);
     for (int i = 0; i < A; ++i) {
       const double normal = dist(s.engine);
@@ -98,6 +107,50 @@ extern "C" int ddrl_agents_destroy(ddrl_agents_t *h) {
   return DDRL_OK;
 }
 
+// the keys both agents read around their nets: ARLAgent.hpp:142-159 + noise / gaussian_policy
+static int read_common(ddrl_agents *h, const char *ini_path, DdrlIni &ini) {
+  std::string err;
+  if (!ini.load(ini_path, &err)) return ddrl_fail(DDRL_EIO, "%s", err.c_str());
+  try {
+    h->decision_each = (int)ini.get_long("agent.decision_each");          // ARLAgent.hpp:143
+    h->noise = ini.get_double("agent.noise");                             // DeepQNAg.hpp:170-171, OfflineCaclaAg.hpp:126-127
+    h->gaussian_policy = (int)ini.get_long("agent.gaussian_policy");
+    if (ini.has("agent.reward_scale")) h->reward_scale = ini.get_double("agent.reward_scale");
+    if (ini.has("agent.history_size") && ini.get_long("agent.history_size") != 1)
+      return ddrl_fail(DDRL_EINVAL, "agent.history_size != 1 is not supported");
+    if (h->gaussian_policy == 2 || (h->algo == 1 && h->gaussian_policy == 4)) {   // DeepQNAg.hpp:203-207, OfflineCaclaAg.hpp:147-156
+      h->noise2 = ini.get_double("agent.noise2");
+      h->noise3 = ini.get_double("agent.noise3");
+    } else if (h->algo == 1 && h->gaussian_policy == 3) {
+      h->noise2 = ini.get_double("agent.noise2");
+    }
+    if (h->algo == 1 && ini.has("agent.update_each_episode")) h->update_each_episode = (int)ini.get_long("agent.update_each_episode");
+  } catch (const std::exception &e) {
+    return ddrl_fail(DDRL_EIO, "%s: %s", ini_path, e.what());
+  }
+  if (h->decision_each < 1) return ddrl_fail(DDRL_EINVAL, "agent.decision_each < 1");
+  if (h->update_each_episode < 1) return ddrl_fail(DDRL_EINVAL, "agent.update_each_episode < 1");
+  return DDRL_OK;
+}
+
+static void init_state(ddrl_agents *h, int G, int S, int A, uint64_t seed) {
+  h->G = G; h->S = S; h->A = A;
+  h->ag.resize(G);
+  for (int g = 0; g < G; ++g) {
+    h->ag[g].engine.seed((uint32_t)(seed * 2654435761ull + 2u * g + 1u));
+    h->ag[g].ou_x.assign(A, 0.);
+  }
+  h->last_state.assign((size_t)G * S, 0.f);
+  h->last_action.assign((size_t)G * A, 0.f);
+  h->last_pure.assign((size_t)G * A, 0.f);
+  h->returned_ac.assign((size_t)G * A, 0.f);
+  h->pure.assign((size_t)G * A, 0.f);
+  h->rew.assign(G, 0.f);
+  h->insert_mask.assign(G, 0);
+  h->goal.assign(G, 0);
+  h->ret_double.assign(A, 0.);
+}
+
 extern "C" int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int device,
                                        uint64_t seed, ddrl_agents_t **out) {
   if (!ini_path || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
@@ -109,44 +162,45 @@ extern "C" int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int n
   if (rc) return rc;
   std::unique_ptr<ddrl_agents> h(new ddrl_agents());
   DdrlIni ini;
-  std::string err;
-  if (!ini.load(ini_path, &err)) return ddrl_fail(DDRL_EIO, "%s", err.c_str());
-  try {
-    h->gamma = cfg.gamma;
-    h->decision_each = (int)ini.get_long("agent.decision_each");          // ARLAgent.hpp:143
-    h->noise = ini.get_double("agent.noise");                             // DeepQNAg.hpp:170-171
-    h->gaussian_policy = (int)ini.get_long("agent.gaussian_policy");
-    if (ini.has("agent.reward_scale")) h->reward_scale = ini.get_double("agent.reward_scale");
-    if (ini.has("agent.history_size") && ini.get_long("agent.history_size") != 1)
-      return ddrl_fail(DDRL_EINVAL, "agent.history_size != 1 is not supported");
-    if (h->gaussian_policy == 2) {                                        // :203-207
-      h->noise2 = ini.get_double("agent.noise2");
-      h->noise3 = ini.get_double("agent.noise3");
-    }
-  } catch (const std::exception &e) {
-    return ddrl_fail(DDRL_EIO, "%s: %s", ini_path, e.what());
-  }
-  if (h->decision_each < 1) return ddrl_fail(DDRL_EINVAL, "agent.decision_each < 1");
+  if ((rc = read_common(h.get(), ini_path, ini))) return rc;
+  h->gamma = cfg.gamma;
   if ((rc = ddrl_ddpg_create(&cfg, seed, &h->pop))) return rc;
-  const int G = cfg.n_agents, S = cfg.nb_sensors, A = cfg.nb_motors;
-  h->G = G; h->S = S; h->A = A;
   h->force_more_update = cfg.force_more_update;
-  h->ag.resize(G);
-  std::vector<uint32_t> rs(G);
-  for (int g = 0; g < G; ++g) {
-    h->ag[g].engine.seed((uint32_t)(seed * 2654435761ull + 2u * g + 1u));
-    h->ag[g].ou_x.assign(A, 0.);
-    rs[g] = (uint32_t)(seed * 40503ull + 7919u * g + 17u);
-  }
+  init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
+  std::vector<uint32_t> rs(cfg.n_agents);
+  for (int g = 0; g < cfg.n_agents; ++g) rs[g] = (uint32_t)(seed * 40503ull + 7919u * g + 17u);
   if ((rc = ddrl_pop_seed_replay(h->pop, rs.data()))) { ddrl_agents_destroy(h.release()); return rc; }
-  h->last_state.assign((size_t)G * S, 0.f);
-  h->last_action.assign((size_t)G * A, 0.f);
-  h->returned_ac.assign((size_t)G * A, 0.f);
-  h->pure.assign((size_t)G * A, 0.f);
-  h->rew.assign(G, 0.f);
-  h->insert_mask.assign(G, 0);
-  h->goal.assign(G, 0);
-  h->ret_double.assign(A, 0.);
+  *out = h.release();
+  return DDRL_OK;
+}
+
+// OfflineCaclaAg (agent/cacla/include/OfflineCaclaAg.hpp:59-62, 122-209).  max_trajectory <= 0: the
+// buffer is sized from environment.max_step_per_instance / decision_each x update_each_episode when the
+// ini has it, 1024 x update_each_episode otherwise.
+extern "C" int ddrl_agents_create_nfac(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int max_trajectory,
+                                       int device, uint64_t seed, ddrl_agents_t **out) {
+  if (!ini_path || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  *out = nullptr;
+  std::unique_ptr<ddrl_agents> h(new ddrl_agents());
+  h->algo = 1;
+  DdrlIni ini;
+  int rc = read_common(h.get(), ini_path, ini);
+  if (rc) return rc;
+  if (max_trajectory <= 0) {
+    long steps = 1024;
+    try {
+      if (ini.has("environment.max_step_per_instance")) steps = (ini.get_long("environment.max_step_per_instance") + h->decision_each - 1) / h->decision_each;
+    } catch (const std::exception &e) { return ddrl_fail(DDRL_EIO, "%s: %s", ini_path, e.what()); }
+    max_trajectory = (int)std::min<long>(steps * h->update_each_episode, 32768);
+  }
+  ddrl_nfac_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.n_agents = n_agents; cfg.nb_sensors = nb_sensors; cfg.nb_motors = nb_motors; cfg.device = device;
+  cfg.max_trajectory = max_trajectory;
+  if ((rc = ddrl_nfac_config_from_ini(ini_path, &cfg))) return rc;
+  h->gamma = cfg.gamma;
+  if ((rc = ddrl_nfac_create(&cfg, seed, &h->pop))) return rc;
+  init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
   *out = h.release();
   return DDRL_OK;
 }
@@ -213,17 +267,22 @@ extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const floa
     // next_action = ann_testing->computeOut(sensors) with the weights BEFORE this step's update (:126)
     int rc = ddrl_pop_infer(h->pop, states, h->pure.data());
     if (rc) return rc;
-    if (any_insert) {
+    if (any_insert && h->algo == 0) {
       // insertSample: push {last_state, last_action, sensors, reward, goal}, then end_episode(true) (:159-165)
       if ((rc = ddrl_pop_replay_append(h->pop, h->last_state.data(), h->last_action.data(), h->rew.data(), states,
                                        h->goal.data(), h->insert_mask.data()))) return rc;
       if ((rc = update_round(h, h->insert_mask.data()))) return rc;
+    } else if (any_insert) {
+      // trajectory.push_back({last_state, last_pure_action, last_action, sensors, reward, goal}) (OfflineCaclaAg.hpp:84-85)
+      if ((rc = ddrl_nfac_traj_append(h->pop, h->last_state.data(), h->last_pure.data(), h->last_action.data(), states,
+                                      h->rew.data(), h->goal.data(), h->insert_mask.data()))) return rc;
     }
     for (int g = 0; g < G; ++g) {
       if (!decide[g]) continue;
       AgentState &s = h->ag[g];
       float *act = &h->returned_ac[(size_t)g * A];
       memcpy(act, &h->pure[(size_t)g * A], A * sizeof(float));
+      memcpy(&h->last_pure[(size_t)g * A], act, A * sizeof(float));
       if (learning[g]) explore(h, g, act);
       memcpy(&h->last_action[(size_t)g * A], act, A * sizeof(float));
       memcpy(&h->last_state[(size_t)g * S], states + (size_t)g * S, S * sizeof(float));
@@ -254,8 +313,25 @@ extern "C" int ddrl_agents_end_episode(ddrl_agents_t *h, const uint8_t *learning
     if (learning[g]) { lm[g] = 1; any_l = true; } else { tm[g] = 1; any_t = true; }
   }
   int rc;
-  if (any_l && (rc = update_round(h, lm.data()))) return rc;
   const int method = h->pop->cfg.ewc_best_param_method;
+  if (h->algo == 1) {
+    // OfflineCaclaAg::end_episode (OfflineCaclaAg.hpp:403-595) + end_instance (:597-600)
+    if (h->pop->cfg.ewc >= 0.) {
+      if (any_t && method >= 4 && (rc = ddrl_pop_update_best_param(h->pop, score.data(), tm.data()))) return rc;
+      if (any_l && method <= 3 && (rc = ddrl_pop_update_best_param(h->pop, score.data(), lm.data()))) return rc;
+    }
+    if (any_l) {
+      if ((rc = ddrl_nfac_episode_end(h->pop, lm.data()))) return rc;               // trajectory_end_points.push_back (:419)
+      std::vector<uint8_t> um(G, 0);
+      bool any_u = false;
+      for (int g = 0; g < G; ++g)
+        if (lm[g] && h->ag[g].episode % h->update_each_episode == 0) { um[g] = 1; any_u = true; }   // :420-421
+      if (any_u && (rc = ddrl_nfac_update(h->pop, um.data()))) return rc;
+    }
+    for (int g = 0; g < G; ++g) if (lm[g]) h->ag[g].episode++;
+    return ddrl_pop_sync(h->pop);
+  }
+  if (any_l && (rc = update_round(h, lm.data()))) return rc;
   if (h->pop->cfg.ewc >= 0.) {
     if (any_l && method <= 3 && (rc = ddrl_pop_update_best_param(h->pop, score.data(), lm.data()))) return rc;
     if (any_l && (rc = ddrl_pop_ewc_decay_update(h->pop, lm.data()))) return rc;
@@ -280,6 +356,7 @@ extern "C" int ddrl_agents_stats(ddrl_agents_t *h, double *sum_weighted_reward, 
 // ---------------------------------------------------------------------------------------------
 struct DDPGAgShim {
   unsigned nb_motors, nb_sensors;
+  int algo = 0;
   ddrl_agents *ag = nullptr;
 };
 
@@ -305,8 +382,9 @@ extern "C" void DDPGAg_unique_invoke(int64_t hnd, int argc, char **argv) {
     else if (a.rfind("--config=", 0) == 0) config = a.substr(9);
     else if (a == "--seed" && i + 1 < argc && argv[i + 1]) seed = strtoull(argv[++i], nullptr, 10);
   }
-  if (ddrl_agents_create_ddpg(config.c_str(), 1, (int)s->nb_sensors, (int)s->nb_motors, -1, seed, &s->ag) != DDRL_OK)
-    fprintf(stderr, "DDPGAg_unique_invoke: %s\n", ddrl_last_error());
+  const int rc = s->algo == 0 ? ddrl_agents_create_ddpg(config.c_str(), 1, (int)s->nb_sensors, (int)s->nb_motors, -1, seed, &s->ag)
+                              : ddrl_agents_create_nfac(config.c_str(), 1, (int)s->nb_sensors, (int)s->nb_motors, 0, -1, seed, &s->ag);
+  if (rc != DDRL_OK) fprintf(stderr, "%s_unique_invoke: %s\n", s->algo == 0 ? "DDPGAg" : "OfflineCaclaAg", ddrl_last_error());
 }
 
 extern "C" void DDPGAg_start_episode(int64_t hnd, const double *state, bool learning) {
@@ -361,7 +439,7 @@ static int save_load(DDPGAgShim *s, int episode, bool save) {
   FILE *f = fopen(path.c_str(), save ? "wb" : "rb");
   if (!f) return ddrl_fail(DDRL_EIO, "cannot open %s", path.c_str());
   int rc = DDRL_OK;
-  for (int net = 0; net < 4 && rc == DDRL_OK; ++net) {
+  for (int net = 0; net < (s->algo == 0 ? 4 : 2) && rc == DDRL_OK; ++net) {
     const int n = ddrl_pop_num_params(s->ag->pop, net);
     std::vector<double> w(n);
     if (save) {
@@ -393,3 +471,22 @@ extern "C" void DDPGAg_delete(int64_t hnd) {
   ddrl_agents_destroy(s->ag);
   delete s;
 }
+
+// NFAC(lambda)-V: the same C flavour under the reference's names (agent/cacla/src/pybinding/nfac.cpp:17-97;
+// gym/agent.py:17-62)
+extern "C" int64_t OfflineCaclaAg_new(unsigned nb_motors, unsigned nb_sensors) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)DDPGAg_new(nb_motors, nb_sensors);
+  s->algo = 1;
+  return (int64_t)(intptr_t)s;
+}
+extern "C" void OfflineCaclaAg_unique_invoke(int64_t ag, int argc, char **argv) { DDPGAg_unique_invoke(ag, argc, argv); }
+extern "C" void OfflineCaclaAg_start_episode(int64_t ag, const double *state, bool learning) { DDPGAg_start_episode(ag, state, learning); }
+extern "C" const double *OfflineCaclaAg_run(int64_t ag, double reward, const double *sensors, bool learning, bool goal_reached, bool last) {
+  return DDPGAg_run(ag, reward, sensors, learning, goal_reached, last);
+}
+extern "C" void OfflineCaclaAg_end_episode(int64_t ag, bool learning) { DDPGAg_end_episode(ag, learning); }
+extern "C" void OfflineCaclaAg_dump(int64_t ag, bool learning, int episode, int step, double treward) { DDPGAg_dump(ag, learning, episode, step, treward); }
+extern "C" void OfflineCaclaAg_display(int64_t ag, bool learning, int episode, int step, double treward) { DDPGAg_display(ag, learning, episode, step, treward); }
+extern "C" void OfflineCaclaAg_save(int64_t ag, int episode) { DDPGAg_save(ag, episode); }
+extern "C" void OfflineCaclaAg_load(int64_t ag, int episode) { DDPGAg_load(ag, episode); }
+extern "C" void OfflineCaclaAg_delete(int64_t ag) { DDPGAg_delete(ag); }

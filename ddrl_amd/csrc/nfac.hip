@@ -282,6 +282,11 @@ extern "C" int ddrl_nfac_traj_len(ddrl_pop_t *h, int32_t *len) {
   return DDRL_OK;
 }
 
+extern "C" int ddrl_nfac_max_trajectory(ddrl_pop_t *h) {
+  if (!h || h->algo != 1 || !h->nfac) return ddrl_fail(DDRL_EINVAL, "not an NFAC population");
+  return h->nfac->cfg.max_trajectory;
+}
+
 // update_critic (OfflineCaclaAg.hpp:242-401): number_fitted_iteration x {targets, stoch_iter_critic steps}
 static int launch_critic(ddrl_pop *h, NfacHost *n, int chunks, int maxlen, int &steps) {
   const ddrl_nfac_config &c = n->cfg;

@@ -88,6 +88,7 @@ SYMBOLS = [
     ("ddrl_pop_debug_stamps", _i, [_vp, _i, _vp]),
     ("ddrl_pop_set_option", _i, [_vp, _cp, _i]),
     ("ddrl_agents_create_ddpg", _i, [_cp, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_agents_create_nfac", _i, [_cp, _i, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
     ("ddrl_agents_destroy", _i, [_vp]),
     ("ddrl_agents_population", _vp, [_vp]),
     ("ddrl_agents_start_episode", _i, [_vp, _vp, _vp, _vp]),
@@ -104,6 +105,16 @@ SYMBOLS = [
     ("DDPGAg_save", None, [C.c_int64, _i]),
     ("DDPGAg_load", None, [C.c_int64, _i]),
     ("DDPGAg_delete", None, [C.c_int64]),
+    ("OfflineCaclaAg_new", C.c_int64, [C.c_uint, C.c_uint]),
+    ("OfflineCaclaAg_unique_invoke", None, [C.c_int64, _i, C.POINTER(_cp)]),
+    ("OfflineCaclaAg_start_episode", None, [C.c_int64, _vp, C.c_bool]),
+    ("OfflineCaclaAg_run", _vp, [C.c_int64, C.c_double, _vp, C.c_bool, C.c_bool, C.c_bool]),
+    ("OfflineCaclaAg_end_episode", None, [C.c_int64, C.c_bool]),
+    ("OfflineCaclaAg_dump", None, [C.c_int64, C.c_bool, _i, _i, C.c_double]),
+    ("OfflineCaclaAg_display", None, [C.c_int64, C.c_bool, _i, _i, C.c_double]),
+    ("OfflineCaclaAg_save", None, [C.c_int64, _i]),
+    ("OfflineCaclaAg_load", None, [C.c_int64, _i]),
+    ("OfflineCaclaAg_delete", None, [C.c_int64]),
     ("ddrl_nfac_config_default", _i, [C.POINTER(NfacConfigC)]),
     ("ddrl_nfac_config_from_ini", _i, [_cp, C.POINTER(NfacConfigC)]),
     ("ddrl_nfac_create", _i, [C.POINTER(NfacConfigC), C.c_uint64, C.POINTER(_vp)]),
@@ -111,6 +122,7 @@ SYMBOLS = [
     ("ddrl_nfac_traj_load", _i, [_vp, _i, _i, _vp, _i, _vp]),
     ("ddrl_nfac_episode_end", _i, [_vp, _vp]),
     ("ddrl_nfac_traj_len", _i, [_vp, _vp]),
+    ("ddrl_nfac_max_trajectory", _i, [_vp]),
     ("ddrl_nfac_update", _i, [_vp, _vp]),
     ("ddrl_nfac_last", _i, [_vp, _vp, _vp, _vp]),
     ("ddrl_cmaes_create", _i, [_i, _vp, _vp, C.c_long, _i, _i, C.POINTER(_vp)]),

@@ -166,6 +166,12 @@ typedef struct ddrl_agents ddrl_agents_t;
  * gaussian_policy, decision_each, reward_scale, noise2, noise3 */
 int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int device,
                             uint64_t seed, ddrl_agents_t **out);
+/* same front end over an NFAC(lambda)-V population: OfflineCaclaAg::_run (OfflineCaclaAg.hpp:79-119:
+ * trajectory push, gaussian_policy 1-4 or e-greedy) and end_episode / end_instance (:403-600:
+ * best-param bookkeeping, trajectory_end_points, the update every agent.update_each_episode episodes).
+ * max_trajectory <= 0: sized from environment.max_step_per_instance when the ini has it. */
+int ddrl_agents_create_nfac(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int max_trajectory,
+                            int device, uint64_t seed, ddrl_agents_t **out);
 int ddrl_agents_destroy(ddrl_agents_t *h);
 /* the population underneath (weights, Adam state, EWC life-cycle); owned by the front end */
 ddrl_pop_t *ddrl_agents_population(ddrl_agents_t *h);
@@ -196,6 +202,17 @@ void DDPGAg_display(int64_t ag, bool learning, int episode, int step, double tre
 void DDPGAg_save(int64_t ag, int episode);
 void DDPGAg_load(int64_t ag, int episode);
 void DDPGAg_delete(int64_t ag);
+/* and the NFAC(lambda)-V twin (agent/cacla/src/pybinding/nfac.cpp:17-97; gym/agent.py:17-62) */
+int64_t OfflineCaclaAg_new(unsigned nb_motors, unsigned nb_sensors);
+void OfflineCaclaAg_unique_invoke(int64_t ag, int argc, char **argv);
+void OfflineCaclaAg_start_episode(int64_t ag, const double *state, bool learning);
+const double *OfflineCaclaAg_run(int64_t ag, double reward, const double *sensors, bool learning, bool goal_reached, bool last);
+void OfflineCaclaAg_end_episode(int64_t ag, bool learning);
+void OfflineCaclaAg_dump(int64_t ag, bool learning, int episode, int step, double treward);
+void OfflineCaclaAg_display(int64_t ag, bool learning, int episode, int step, double treward);
+void OfflineCaclaAg_save(int64_t ag, int episode);
+void OfflineCaclaAg_load(int64_t ag, int episode);
+void OfflineCaclaAg_delete(int64_t ag);
 
 /* ------------------------------------------------------------------------------------------------
  * NFAC(lambda)-V (agent/cacla/include/OfflineCaclaAg.hpp): population of G independent agents,
@@ -235,6 +252,8 @@ int ddrl_nfac_traj_load(ddrl_pop_t *h, int agent, int n, const float *rows, int 
 /* trajectory_end_points.push_back(trajectory.size()) (OfflineCaclaAg.hpp:419) */
 int ddrl_nfac_episode_end(ddrl_pop_t *h, const uint8_t *mask);
 int ddrl_nfac_traj_len(ddrl_pop_t *h, int32_t *len /* [G] */);
+/* capacity of every agent's trajectory buffer in transitions (> 0), or a negative DDRL_E* code */
+int ddrl_nfac_max_trajectory(ddrl_pop_t *h);
 /* the learning branch of OfflineCaclaAg::end_episode after the update_each_episode gate
  * (OfflineCaclaAg.hpp:423-594) for every agent with mask[g] != 0: critic fits (update_critic,
  * :242-401: TD(0) or lambda-return targets, number_fitted_iteration x stoch_iter_critic full-batch

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "ddrl_pop.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(ddrl_[a-z0-9_]+|DDPGAg_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(ddrl_[a-z0-9_]+|DDPGAg_[a-z_]+|OfflineCaclaAg_[a-z_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
