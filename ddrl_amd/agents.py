@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _l
-from .population import NfacPopulation, Population, _p
+from .population import NfacPopulation, PolicyPopulation, Population, _p
 
 
 class _Borrowed(Population):
@@ -89,6 +89,38 @@ class NfacAgents(_Agents):
         self.pop.maxT = self.L.ddrl_nfac_max_trajectory(self.pop.h)
         if self.pop.maxT < 0:
             _l.check(self.pop.maxT)
+
+
+class _BorrowedPolicy(_Borrowed, PolicyPopulation):
+    pass
+
+
+class CmaesAgents(_Agents):
+    """CMAESAg with one agent slot per individual of the generation (ddrl_agents_create_cmaes):
+    start_episode = start_instance, end_episode = end_episode + end_instance."""
+    _view = _BorrowedPolicy
+
+    def __init__(self, ini_path, nb_sensors, nb_motors, seed=0, device=-1):
+        from .cmaes import Cmaes
+        self.L = _l.load()
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_agents_create_cmaes(ini_path.encode(), nb_sensors, nb_motors, device, seed, C.byref(h)))
+        lam = C.c_int()
+        _l.check(self.L.ddrl_agents_cmaes_state(h, C.byref(lam), None, None, None))
+        self._adopt(h, lam.value, nb_sensors, nb_motors)
+        self.es = Cmaes.borrow(self.L.ddrl_agents_cmaes(h), self.pop.num_params(0))
+
+    def state(self):
+        v = [C.c_int() for _ in range(4)]
+        _l.check(self.L.ddrl_agents_cmaes_state(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("lambda", "n_evaluated", "generations", "error_count"), [x.value for x in v]))
+
+    def close(self):
+        if getattr(self, "es", None):
+            self.es.close()
+        _Agents.close(self)
+
+    __del__ = close
 
 
 class DDRLAg:

@@ -24,9 +24,18 @@ class Cmaes:
         self.lam = int(self.get("lambda"))
         self.mu = int(self.get("mu"))
 
+    @classmethod
+    def borrow(cls, handle, N):
+        """view of a handle owned elsewhere (ddrl_agents_cmaes); close() does not destroy it"""
+        self = cls.__new__(cls)
+        self._L, self._h, self.N, self._borrowed = _l.load(), C.c_void_p(handle), int(N), True
+        self.lam, self.mu = int(self.get("lambda")), int(self.get("mu"))
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.ddrl_cmaes_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._L.ddrl_cmaes_destroy(self._h)
             self._h = None
 
     __del__ = close

@@ -1,4 +1,4 @@
-// agents.hip -- the agent-level front end over a DDPG population: what ARLAgent::runf /
+// agents.hip -- the agent-level front end over a DDPG / NFAC / CMA-ES population: what ARLAgent::runf /
 // start_episode (common/include/arch/ARLAgent.hpp:37-137) and DeepQNAg::_run / _start_episode /
 // end_episode / end_instance (agent/deepqn/include/DeepQNAg.hpp:122-165, 237-317) do around the nets,
 // for G agents at once, plus the G = 1 C flavour with the reference's own names and argument types
@@ -27,8 +27,15 @@ struct ddrl_agents {
   int G = 0, S = 0, A = 0;
   double gamma = 0.99, noise = 0., noise2 = 0., noise3 = 0., reward_scale = 1.;
   int gaussian_policy = 0, decision_each = 1, force_more_update = 0;
-  int algo = 0;                              // 0 DDPG (DeepQNAg), 1 NFAC (OfflineCaclaAg)
+  int algo = 0;                              // 0 DDPG (DeepQNAg), 1 NFAC (OfflineCaclaAg), 2 CMA-ES (CMAESAg)
   int update_each_episode = 1;
+  // CMAESAg: one agent slot per individual of the generation
+  ddrl_cmaes_t *es = nullptr;
+  float *d_best = nullptr;                   // xbestever as fp32 (loadPolicyParameters(getBestSolution()))
+  std::vector<double> funvals;               // arFunvals
+  std::vector<uint8_t> evaluated;
+  int n_evaluated = 0, generations = 0, error_count = 0;
+  bool done_once = false, check_feasible = true, racing = false;
   std::vector<AgentState> ag;
   std::vector<float> last_state, last_action, last_pure, returned_ac, pure, rew;   // [G x S], [G x A] x 4, [G]
   std::vector<uint8_t> insert_mask, goal;
@@ -102,6 +109,8 @@ static void explore(ddrl_agents *h, int g, float *act) {
 
 extern "C" int ddrl_agents_destroy(ddrl_agents_t *h) {
   if (!h) return DDRL_OK;
+  if (h->d_best) (void)hipFree(h->d_best);
+  if (h->es) ddrl_cmaes_destroy(h->es);
   if (h->pop) ddrl_pop_destroy(h->pop);
   delete h;
   return DDRL_OK;
@@ -113,8 +122,10 @@ static int read_common(ddrl_agents *h, const char *ini_path, DdrlIni &ini) {
   if (!ini.load(ini_path, &err)) return ddrl_fail(DDRL_EIO, "%s", err.c_str());
   try {
     h->decision_each = (int)ini.get_long("agent.decision_each");          // ARLAgent.hpp:143
-    h->noise = ini.get_double("agent.noise");                             // DeepQNAg.hpp:170-171, OfflineCaclaAg.hpp:126-127
-    h->gaussian_policy = (int)ini.get_long("agent.gaussian_policy");
+    if (h->algo != 2) {                                                   // CMAESAg explores in parameter space (CMAESAg.hpp:43)
+      h->noise = ini.get_double("agent.noise");                           // DeepQNAg.hpp:170-171, OfflineCaclaAg.hpp:126-127
+      h->gaussian_policy = (int)ini.get_long("agent.gaussian_policy");
+    }
     if (ini.has("agent.reward_scale")) h->reward_scale = ini.get_double("agent.reward_scale");
     if (ini.has("agent.history_size") && ini.get_long("agent.history_size") != 1)
       return ddrl_fail(DDRL_EINVAL, "agent.history_size != 1 is not supported");
@@ -205,7 +216,129 @@ extern "C" int ddrl_agents_create_nfac(const char *ini_path, int n_agents, int n
   return DDRL_OK;
 }
 
+// CMAESAg::new_population (CMAESAg.hpp:144-172)
+static int new_population(ddrl_agents *h) {
+  char msg[256];
+  int n = ddrl_cmaes_test_for_termination(h->es, msg, (int)sizeof(msg));
+  if (n < 0) return n;
+  if (n > 0) {
+    fprintf(stderr, "mismatch %s\n", msg);           // LOG_INFO("mismatch " << terminate)
+    h->error_count++;
+    if (h->error_count > 20 && h->racing)
+      return ddrl_fail(DDRL_ESTATE, "CMA-ES met a stopping criterion more than 20 times with agent.racing set (the reference exits here)");
+  }
+  int rc = ddrl_cmaes_sample(h->es);
+  if (rc) return rc;
+  if (h->check_feasible) {
+    int resampled = 0;
+    if ((rc = ddrl_cmaes_make_feasible(h->es, 500., &resampled))) return rc;   // is_feasible: |x_i| < 500 (:135-142)
+    if (resampled) fprintf(stderr, "non feasible solution produced\n");
+  }
+  std::fill(h->evaluated.begin(), h->evaluated.end(), 0);
+  h->n_evaluated = 0;
+  return DDRL_OK;
+}
+
+// CMAESAg (agent/cmaes/include/CMAESAg.hpp:50-133): the policy net from the [agent] keys, c-cmaes
+// started at its initial weights with deviation agent.initial_deviation.  One agent slot per
+// individual: G = lambda policies are evaluated side by side (the reference evaluates them one
+// episode after the other; a mask with one bit set reproduces that order).
+extern "C" int ddrl_agents_create_cmaes(const char *ini_path, int nb_sensors, int nb_motors, int device, uint64_t seed,
+                                        ddrl_agents_t **out) {
+  if (!ini_path || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  *out = nullptr;
+  std::unique_ptr<ddrl_agents> h(new ddrl_agents());
+  h->algo = 2;
+  DdrlIni ini;
+  int rc = read_common(h.get(), ini_path, ini);
+  if (rc) return rc;
+  std::vector<long> hid;
+  long population = 0, hidden_type = 1, out_type = 0;
+  double deviation = 0.;
+  try {
+    h->gamma = ini.get_double("agent.gamma");                                    // ARLAgent.hpp:141
+    hid = ini.get_list("agent.hidden_unit_a");                                   // CMAESAg.hpp:51-56
+    hidden_type = ini.get_long("agent.actor_hidden_layer_type");
+    out_type = ini.get_long("agent.actor_output_layer_type");
+    if (ini.get_long("agent.batch_norm") != 0) return ddrl_fail(DDRL_EINVAL, "agent.batch_norm != 0 is not supported");
+    population = ini.get_long("agent.population");
+    deviation = ini.get_double("agent.initial_deviation");
+    if (ini.has("agent.check_feasible")) h->check_feasible = ini.get_bool("agent.check_feasible");   // :64-77
+    if (ini.has("agent.racing")) h->racing = ini.get_bool("agent.racing");
+    if (ini.has("devnn.ewc") && ini.get_double("devnn.ewc") >= 0.)
+      return ddrl_fail(DDRL_EINVAL, "CMA-ES doesn't rely on gradient (devnn.ewc must be < 0, CMAESAg.hpp:124-131)");
+  } catch (const std::exception &e) {
+    return ddrl_fail(DDRL_EIO, "%s: %s", ini_path, e.what());
+  }
+  if (hid.empty() || hid.size() > DDRL_MAX_HIDDEN) return ddrl_fail(DDRL_EINVAL, "hidden_unit_a: 1..%d layers supported", DDRL_MAX_HIDDEN);
+  if (!(deviation > 0.)) return ddrl_fail(DDRL_EINVAL, "agent.initial_deviation <= 0");
+  int hidden[DDRL_MAX_HIDDEN];
+  long N = 0, prev = nb_sensors;
+  for (size_t i = 0; i < hid.size(); ++i) { hidden[i] = (int)hid[i]; N += (prev + 1) * hid[i]; prev = hid[i]; }
+  N += (prev + 1) * nb_motors;
+  // cmaes_init: lambda < 2 => 4 + (int)(3 log N) (cmaes.c readpara_SupplementDefaults; CMAESAg.hpp:108-109)
+  const int lambda = population >= 2 ? (int)population : 4 + (int)(3. * std::log((double)N));
+  if ((rc = ddrl_policy_create(lambda, nb_sensors, nb_motors, hidden, (int)hid.size(), (int)hidden_type, (int)out_type, device,
+                               seed, &h->pop))) return rc;
+  if (ddrl_pop_num_params(h->pop, DDRL_NET_ACTOR) != N) { ddrl_agents_destroy(h.release()); return ddrl_fail(DDRL_ESTATE, "parameter count mismatch"); }
+  {
+    std::vector<double> w((size_t)lambda * N), stds((size_t)N, deviation);
+    if ((rc = ddrl_pop_get_weights(h->pop, DDRL_NET_ACTOR, w.data()))) { ddrl_agents_destroy(h.release()); return rc; }
+    // startx = the net's initial weights (:95); the reference passes seed 0 = clock to cmaes_init (:98)
+    if ((rc = ddrl_cmaes_create((int)N, w.data(), stds.data(), (long)(seed % 2147483646ull) + 1, lambda, h->pop->device, &h->es))) {
+      ddrl_agents_destroy(h.release());
+      return rc;
+    }
+  }
+  if (hipMalloc((void **)&h->d_best, (size_t)N * sizeof(float)) != hipSuccess) { ddrl_agents_destroy(h.release()); return ddrl_fail(DDRL_ENOMEM, "hipMalloc failed"); }
+  init_state(h.get(), lambda, nb_sensors, nb_motors, seed);
+  h->funvals.assign(lambda, 0.);
+  h->evaluated.assign(lambda, 0);
+  if ((rc = new_population(h.get()))) { ddrl_agents_destroy(h.release()); return rc; }
+  *out = h.release();
+  return DDRL_OK;
+}
+
 extern "C" ddrl_pop_t *ddrl_agents_population(ddrl_agents_t *h) { return h ? h->pop : nullptr; }
+extern "C" ddrl_cmaes_t *ddrl_agents_cmaes(ddrl_agents_t *h) { return h ? h->es : nullptr; }
+
+extern "C" int ddrl_agents_cmaes_state(ddrl_agents_t *h, int *lambda, int *n_evaluated, int *generations, int *error_count) {
+  if (!h || h->algo != 2) return ddrl_fail(DDRL_EINVAL, "not a CMA-ES front end");
+  if (lambda) *lambda = h->G;
+  if (n_evaluated) *n_evaluated = h->n_evaluated;
+  if (generations) *generations = h->generations;
+  if (error_count) *error_count = h->error_count;
+  return DDRL_OK;
+}
+
+// CMAESAg::start_instance (CMAESAg.hpp:212-225): individual g of the current generation goes into
+// policy g while learning or before the first distribution update, the best-ever solution afterwards
+static int cmaes_start_instance(ddrl_agents *h, const uint8_t *learning, const uint8_t *mask) {
+  const int G = h->G;
+  std::vector<uint8_t> mp(G, 0), mb(G, 0);
+  bool any_p = false, any_b = false;
+  for (int g = 0; g < G; ++g) {
+    if (mask && !mask[g]) continue;
+    if (learning[g] || !h->done_once) { mp[g] = 1; any_p = true; } else { mb[g] = 1; any_b = true; }
+    if (learning[g]) h->ag[g].episode++;
+  }
+  int rc;
+  if (any_p) {
+    const float *dX; int ld;
+    if ((rc = ddrl_cmaes_population_dev(h->es, &dX, &ld))) return rc;
+    if ((rc = ddrl_pop_load_flat_dev(h->pop, DDRL_NET_ACTOR, dX, ld, mp.data()))) return rc;
+  }
+  if (any_b) {
+    const int N = ddrl_pop_num_params(h->pop, DDRL_NET_ACTOR);
+    std::vector<double> xb(N);
+    if ((rc = ddrl_cmaes_get_vec(h->es, "xbestever", xb.data()))) return rc;     // getBestSolution (:328-335)
+    std::vector<float> xf(xb.begin(), xb.end());
+    HIPCHK(hipSetDevice(h->pop->device));
+    HIPCHK(hipMemcpy(h->d_best, xf.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = ddrl_pop_load_flat_dev(h->pop, DDRL_NET_ACTOR, h->d_best, 0, mb.data()))) return rc;
+  }
+  return DDRL_OK;
+}
 
 // ARLAgent::start_episode (ARLAgent.hpp:109-137) + DeepQNAg::_start_episode (DeepQNAg.hpp:237-247)
 extern "C" int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states, const uint8_t *learning, const uint8_t *mask) {
@@ -225,6 +358,7 @@ extern "C" int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states, 
     s.have_last = false;
     s.step = 0;
   }
+  if (h->algo == 2) return cmaes_start_instance(h, learning, mask);
   return DDRL_OK;
 }
 
@@ -260,7 +394,7 @@ extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const floa
       h->goal[g] = goal[g] ? 1 : 0;
       decide[g] = 1;
       any = true;
-      if (s.have_last && learning[g]) { h->insert_mask[g] = 1; any_insert = true; }   // DeepQNAg.hpp:128-131
+      if (s.have_last && learning[g] && h->algo != 2) { h->insert_mask[g] = 1; any_insert = true; }   // DeepQNAg.hpp:128-131
     }
   }
   if (any) {
@@ -283,7 +417,7 @@ extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const floa
       float *act = &h->returned_ac[(size_t)g * A];
       memcpy(act, &h->pure[(size_t)g * A], A * sizeof(float));
       memcpy(&h->last_pure[(size_t)g * A], act, A * sizeof(float));
-      if (learning[g]) explore(h, g, act);
+      if (learning[g] && h->algo != 2) explore(h, g, act);
       memcpy(&h->last_action[(size_t)g * A], act, A * sizeof(float));
       memcpy(&h->last_state[(size_t)g * S], states + (size_t)g * S, S * sizeof(float));
       s.have_last = true;
@@ -313,6 +447,22 @@ extern "C" int ddrl_agents_end_episode(ddrl_agents_t *h, const uint8_t *learning
     if (learning[g]) { lm[g] = 1; any_l = true; } else { tm[g] = 1; any_t = true; }
   }
   int rc;
+  if (h->algo == 2) {
+    // CMAESAg::end_episode + end_instance (CMAESAg.hpp:233-253), one episode per instance:
+    // arFunvals[g] = accumulate(scores, 0.f) / size -- a float accumulator
+    for (int g = 0; g < G; ++g) {
+      if (!lm[g]) continue;
+      h->funvals[g] = (double)(0.f + (float)(-score[g]));
+      if (!h->evaluated[g]) { h->evaluated[g] = 1; h->n_evaluated++; }
+    }
+    if (h->n_evaluated >= G) {
+      if ((rc = ddrl_cmaes_update(h->es, h->funvals.data()))) return rc;           // cmaes_UpdateDistribution (:246)
+      h->done_once = true;
+      h->generations++;
+      if ((rc = new_population(h))) return rc;
+    }
+    return DDRL_OK;
+  }
   const int method = h->pop->cfg.ewc_best_param_method;
   if (h->algo == 1) {
     // OfflineCaclaAg::end_episode (OfflineCaclaAg.hpp:403-595) + end_instance (:597-600)

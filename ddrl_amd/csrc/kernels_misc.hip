@@ -185,6 +185,27 @@ extern "C" __global__ void snapshot_kernel(float *__restrict__ dst, const float 
     *(f32x4 *)(dst + off + i) = *(const f32x4 *)(src + off + i);
 }
 
+// MLP::copyWeightsFrom (MLP.hpp:651-676) for every flagged agent, from device memory: row `agent` of
+// flat [G x ld] (ld == 0: one row for all) holds the parameters in learnable_params() order
+// [W1 (out x in), b1, W2, b2, ...]; they go to the tile-major image.  Pad elements are not touched.
+extern "C" __global__ void __launch_bounds__(256)
+load_flat_kernel(NetDesc nd, float *__restrict__ w, const float *__restrict__ flat, int ld, const uint8_t *__restrict__ flag) {
+  const int agent = blockIdx.x;
+  if (flag && !flag[agent]) return;
+  const float *src = flat + (size_t)agent * ld;
+  float *dst = w + (size_t)agent * nd.stride();
+  int base = 0;
+  for (int l = 0; l < nd.L(); ++l) {
+    const int din = nd.d(l), dout = nd.d(l + 1), nw = din * dout;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+      const int n = i / din, c = i - n * din;
+      dst[nd.offw(l) + ddrl_widx(n, c, nd.kp(l))] = src[base + i];
+    }
+    for (int i = threadIdx.x; i < dout; i += blockDim.x) dst[nd.offb(l) + i] = src[base + nw + i];
+    base += nw + dout;
+  }
+}
+
 // ewc_setup (DODevMLP.hpp:604-633): wstar <- best; w <- wstar; fhat <- (F / nbr) / max(F / nbr);
 // F <- 0 (the reference drops the vector: fisher = nullptr), nbr <- 0
 extern "C" __global__ void __launch_bounds__(256)
@@ -261,6 +282,10 @@ extern "C" hipError_t infer_launch(const NetDesc *nd, const float *w, const floa
 }
 extern "C" hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st) {
   hipLaunchKernelGGL(snapshot_kernel, dim3(G), dim3(256), 0, st, dst, src, stride, flag);
+  return hipGetLastError();
+}
+extern "C" hipError_t load_flat_launch(const NetDesc *nd, float *w, const float *flat, int ld, const uint8_t *flag, int G, hipStream_t st) {
+  hipLaunchKernelGGL(load_flat_kernel, dim3(G), dim3(256), 0, st, *nd, w, flat, ld, flag);
   return hipGetLastError();
 }
 extern "C" hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat,

@@ -19,6 +19,7 @@ hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, 
 hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
                               const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
 hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st);
+hipError_t load_flat_launch(const NetDesc *nd, float *w, const float *flat, int ld, const uint8_t *flag, int G, hipStream_t st);
 hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat, float *nbr,
                             int stride, const uint8_t *flag, int G, hipStream_t st);
 hipError_t ewc_cost_launch(const float *w, const float *wstar, const float *fhat, int stride, float *out, int G,
@@ -213,6 +214,75 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   return DDRL_OK;
 }
 
+// Policies only (algo 2): G actor nets and nothing else -- no optimiser state, targets or replay.
+// CMAESAg's `ann` (CMAESAg.hpp:81-82: MLP(nb_sensors, hidden_unit_a, nb_motors, 0.1, 1, hidden type,
+// output type, batch_norm)) for all lambda individuals of a generation at once.
+extern "C" int ddrl_policy_create(int n_agents, int nb_sensors, int nb_motors, const int *hidden, int n_hidden,
+                                  int hidden_layer_type, int output_layer_type, int device, uint64_t init_seed,
+                                  ddrl_pop_t **out) {
+  if (!hidden || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (n_agents < 1) return ddrl_fail(DDRL_EINVAL, "n_agents < 1");
+  if (nb_sensors < 1 || nb_motors < 1 || nb_sensors > DDRL_MAXW || nb_motors > DDRL_MAXW)
+    return ddrl_fail(DDRL_EINVAL, "nb_sensors/nb_motors outside 1..%d", DDRL_MAXW);
+  if (n_hidden < 1 || n_hidden > DDRL_MAX_HIDDEN) return ddrl_fail(DDRL_EINVAL, "1..%d hidden layers supported", DDRL_MAX_HIDDEN);
+  for (int i = 0; i < n_hidden; ++i)
+    if (hidden[i] < 1 || hidden[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden[%d]=%d outside 1..%d", i, hidden[i], DDRL_MAXW);
+  if (hidden_layer_type < 1 || hidden_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "hidden_layer_type not in (1,2,3)");
+  if (output_layer_type < 0 || output_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "output_layer_type not in 0..3");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return ddrl_fail(DDRL_EHIP, "no HIP device: libddrl_pop has no CPU path");
+  ddrl_pop *h = new ddrl_pop();
+  h->algo = 2;
+  memset(&h->cfg, 0, sizeof(h->cfg));
+  h->cfg.n_agents = n_agents; h->cfg.nb_sensors = nb_sensors; h->cfg.nb_motors = nb_motors;
+  h->cfg.n_hidden_a = n_hidden;
+  for (int i = 0; i < n_hidden; ++i) h->cfg.hidden_unit_a[i] = hidden[i];
+  h->cfg.hidden_layer_type = hidden_layer_type; h->cfg.actor_output_layer_type = output_layer_type;
+  h->cfg.ewc = -1.; h->cfg.device = device;
+  h->G = n_agents;
+  if (device >= 0) h->device = device;
+  else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+  auto bail = [&](int code) { ddrl_pop_destroy(h); return code; };
+  int rc;
+  if ((rc = set_device(h))) return bail(rc);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "hipStreamCreate failed"));
+  const size_t G = n_agents;
+  build_desc(h->net[0].nd, nb_sensors, hidden, n_hidden, nb_motors, hidden_layer_type, output_layer_type);
+  if ((rc = dalloc(h, &h->net[0].st.w, G * h->net[0].nd.stride()))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_s, G * nb_sensors))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_act, G * nb_motors))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_mask, G))) return bail(rc);
+  if ((rc = dalloc(h, &h->d_flag, G))) return bail(rc);
+  {
+    std::mt19937_64 eng(init_seed);                    // gaussian(0, 0.01) fill like the learners (MLP.hpp:936-944)
+    std::normal_distribution<double> nd01(0.0, 0.01);
+    std::vector<double> flat(G * h->net[0].nd.np);
+    for (auto &x : flat) x = nd01(eng);
+    if ((rc = upload_flat(h, h->net[0].nd, h->net[0].st.w, flat.data()))) return bail(rc);
+  }
+  *out = h;
+  return DDRL_OK;
+}
+
+// MLP::copyWeightsFrom from device memory (fp32, learnable_params() order): row g of d_flat [G x ld]
+// -> agent g's net; ld == 0 broadcasts one row to every (masked) agent.  This is how a CMA-ES
+// generation (ddrl_cmaes_population_dev) becomes lambda policies without leaving the GPU.  The caller
+// orders the producer of d_flat before this call (the ddrl_cmaes_* calls return synchronised).
+extern "C" int ddrl_pop_load_flat_dev(ddrl_pop_t *h, int net, const float *d_flat, int ld, const uint8_t *mask) {
+  if (!h || !d_flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  const TrainNet *t = train_net(h, net);
+  if (ld != 0 && ld < t->nd.np) return ddrl_fail(DDRL_EINVAL, "ld=%d < %d parameters", ld, t->nd.np);
+  int rc = set_device(h);
+  if (rc) return rc;
+  const uint8_t *dmask;
+  if ((rc = upload_mask(h, mask, &dmask))) return rc;
+  HIPCHK(load_flat_launch(&t->nd, net_weights(h, net), d_flat, ld, dmask, h->G, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
 extern "C" int ddrl_pop_destroy(ddrl_pop_t *h) {
   if (!h) return DDRL_OK;
   (void)hipSetDevice(h->device);
@@ -238,6 +308,7 @@ extern "C" int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *
   const int G = h->G;
   std::vector<float> f(G);
   std::string k(key);
+  if (h->algo == 2) return ddrl_fail(DDRL_ESTATE, "a policies-only population has no hyper-parameters");
   if (k == "alpha_a" || k == "alpha_v") {
     for (int g = 0; g < G; ++g) { if (!(v[g] > 0)) return ddrl_fail(DDRL_EINVAL, "%s[%d] <= 0", key, g); f[g] = (float)v[g]; }
     return upload_vec(h, k == "alpha_a" ? h->net[0].d_lr : h->net[1].d_lr, f);
@@ -275,7 +346,7 @@ extern "C" int ddrl_pop_get_weights(ddrl_pop_t *h, int net, double *flat) {
 }
 
 extern "C" int ddrl_pop_get_adam(ddrl_pop_t *h, int net, double *m, double *v, int32_t *iter) {
-  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic only");
+  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC) || h->algo == 2) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic of a learning population only");
   int rc = set_device(h);
   if (rc) return rc;
   TrainNet *t = train_net(h, net);
@@ -289,7 +360,7 @@ extern "C" int ddrl_pop_get_adam(ddrl_pop_t *h, int net, double *m, double *v, i
 }
 
 extern "C" int ddrl_pop_set_adam(ddrl_pop_t *h, int net, const double *m, const double *v, const int32_t *iter) {
-  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic only");
+  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC) || h->algo == 2) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic of a learning population only");
   int rc = set_device(h);
   if (rc) return rc;
   TrainNet *t = train_net(h, net);

@@ -34,7 +34,7 @@ struct TrainNet {
 };
 
 struct ddrl_pop {
-  int algo = 0;                    // 0 DDPG, 1 NFAC
+  int algo = 0;                    // 0 DDPG, 1 NFAC, 2 policies only (CMA-ES individuals)
   NfacHost *nfac = nullptr;        // algo == 1
   ddrl_ddpg_config cfg;            // NFAC handles fill the fields the shared entry points read
   int G = 0, device = 0;
@@ -211,6 +211,6 @@ static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc, bool target = true) {
 
 
 // NFAC populations have no target nets (OfflineCaclaAg.hpp:186-196)
-static bool bad_net(ddrl_pop *h, int net) { return net < 0 || net > 3 || (h->algo == 1 && net > DDRL_NET_CRITIC); }
+static bool bad_net(ddrl_pop *h, int net) { return net < 0 || net > 3 || (h->algo == 1 && net > DDRL_NET_CRITIC) || (h->algo == 2 && net != DDRL_NET_ACTOR); }
 #define DDPG_ONLY(h) do { if ((h)->algo != 0) return ddrl_fail(DDRL_ESTATE, "%s: DDPG populations only", __func__); } while (0)
 

@@ -89,6 +89,11 @@ SYMBOLS = [
     ("ddrl_pop_set_option", _i, [_vp, _cp, _i]),
     ("ddrl_agents_create_ddpg", _i, [_cp, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
     ("ddrl_agents_create_nfac", _i, [_cp, _i, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_agents_create_cmaes", _i, [_cp, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_agents_cmaes", _vp, [_vp]),
+    ("ddrl_agents_cmaes_state", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_policy_create", _i, [_i, _i, _i, _vp, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_pop_load_flat_dev", _i, [_vp, _i, _vp, _i, _vp]),
     ("ddrl_agents_destroy", _i, [_vp]),
     ("ddrl_agents_population", _vp, [_vp]),
     ("ddrl_agents_start_episode", _i, [_vp, _vp, _vp, _vp]),

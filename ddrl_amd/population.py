@@ -291,3 +291,20 @@ class NfacPopulation(Population):
         loss = np.empty(self.G, np.float32)
         _l.check(self.L.ddrl_nfac_last(self.h, _p(deltas), _p(n), _p(loss)))
         return dict(deltas=deltas, n_pos=n, critic_loss=loss)
+
+
+class PolicyPopulation(Population):
+    """G policy nets and nothing else (ddrl_policy_create): CMAESAg's `ann` for every individual."""
+
+    def __init__(self, n_agents, nb_sensors, nb_motors, hidden, hidden_layer_type=1, output_layer_type=2, device=-1,
+                 init_seed=0):
+        self.L = _l.load()
+        hid = np.ascontiguousarray(hidden, np.int32)
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_policy_create(n_agents, nb_sensors, nb_motors, _p(hid), hid.size, hidden_layer_type,
+                                           output_layer_type, device, init_seed, C.byref(h)))
+        self.h, self.G, self.S, self.A = h, n_agents, nb_sensors, nb_motors
+
+    def load_flat_dev(self, d_flat_ptr, ld, mask=None, net=0):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_load_flat_dev(self.h, net, d_flat_ptr, ld, _p(m)))

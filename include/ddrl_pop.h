@@ -320,6 +320,30 @@ int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int msg_len);
  * eigenbasis: no counterpart in the reference. */
 int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value);
 
+/* CMAESAg (agent/cmaes/include/CMAESAg.hpp) around the two: a policies-only population -- G actor
+ * nets without optimiser state, targets or replay, CMAESAg's `ann` (:81-82) once per individual --
+ * and MLP::copyWeightsFrom (MLP.hpp:651-676, CMAESAg::loadPolicyParameters :324-326) from device
+ * memory: row g of d_flat [G x ld] (fp32, learnable_params() order; ld == 0: one row for all) becomes
+ * agent g's net, so a generation turns into lambda policies without leaving the GPU. */
+int ddrl_policy_create(int n_agents, int nb_sensors, int nb_motors, const int *hidden, int n_hidden,
+                       int hidden_layer_type, int output_layer_type, int device, uint64_t init_seed,
+                       ddrl_pop_t **out);
+int ddrl_pop_load_flat_dev(ddrl_pop_t *h, int net, const float *d_flat, int ld, const uint8_t *mask);
+/* The ddrl_agents_* front end as CMAESAg: _unique_invoke (:50-133: [agent] hidden_unit_a,
+ * actor_hidden_layer_type, actor_output_layer_type, batch_norm = 0, population, initial_deviation,
+ * optional check_feasible / racing; cmaes_init at the net's initial weights + new_population),
+ * ddrl_agents_start_episode = start_instance (:174-226: individual g, or the best-ever solution when
+ * testing after the first update, goes into policy g), ddrl_agents_run = ARLAgent::runf + _run
+ * (:38-47, no action noise), ddrl_agents_end_episode = end_episode + end_instance (:233-253:
+ * arFunvals[g] = -sum_weighted_reward through the reference's float accumulator; once all lambda
+ * individuals are in: cmaes_UpdateDistribution + new_population).  One agent slot per individual:
+ * the generation is evaluated side by side; a mask with one bit set gives the reference's
+ * one-individual-per-episode order.  One episode per instance, as in the reference's gym flavour. */
+int ddrl_agents_create_cmaes(const char *ini_path, int nb_sensors, int nb_motors, int device, uint64_t seed,
+                             ddrl_agents_t **out);
+ddrl_cmaes_t *ddrl_agents_cmaes(ddrl_agents_t *h);            /* borrowed */
+int ddrl_agents_cmaes_state(ddrl_agents_t *h, int *lambda, int *n_evaluated, int *generations, int *error_count);
+
 /* Measurement hooks (no counterpart in the reference, which only records total wall minutes,
  * common/include/arch/Simulator.hpp:127): with profiling on, every ddrl_pop_ddpg_update() brackets
  * its update kernel with HIP events on the handle's stream; ddrl_pop_profile_read() synchronises and
