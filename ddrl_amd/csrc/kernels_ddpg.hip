@@ -119,6 +119,9 @@ ddpg_update_kernel(const DdpgParams P) {
   const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
   const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
   const float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
+#ifdef DDRL_EXP_HOTW      // experiment: every agent's passes read agent 0's weights (always cache-hot)
+  w_a = P.sa.w; w_at = P.sa.wt; w_q = P.sq.w; w_qt = P.sq.wt;
+#endif
 
   // ---- n-step horizon (DeepQNAg.hpp:360-373, 394-402): the horizon stops before a transition that
   // reached the goal and at the end of the replay; rewards of steps [0, valid) are discounted ----

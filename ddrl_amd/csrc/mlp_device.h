@@ -65,6 +65,12 @@ struct BFrag { f32x4 v[DDRL_MAXKC]; float bias; };   // + the tile's bias: waiti
 
 __device__ __forceinline__ void load_bfrag(const float *__restrict__ W, const float *__restrict__ bias, int kp, int N, int nt, int lane, BFrag &b) {
   const int g = lane >> 4, c = lane & 15;
+#ifdef DDRL_EXP_NOWLOAD
+  b.bias = 0.01f * nt;
+#pragma unroll
+  for (int kc = 0; kc < DDRL_MAXKC; ++kc) b.v[kc] = (f32x4){0.01f * (float)lane, 0.02f, -0.01f * (float)kc, 0.03f};
+  return;
+#endif
   b.bias = bias[nt * 16 + c < N ? nt * 16 + c : N - 1];
   // tile-major storage: block (nt, kc) is contiguous and lane (c, g)'s float4 sits at c*kw + 4g, so
   // a full block is one 1-KiB wave load.  Pad rows (n >= N) exist in memory and hold zeros.
@@ -166,6 +172,13 @@ struct WCol { float v[DDRL_MAXKC][4]; };
 
 __device__ __forceinline__ void load_wcol(const float *__restrict__ W, int kp, int N, int kt, int lane, WCol &b) {
   const int g = lane >> 4, c = lane & 15;
+#ifdef DDRL_EXP_NOWLOAD
+#pragma unroll
+  for (int nc = 0; nc < DDRL_MAXKC; ++nc)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.v[nc][j] = 0.01f * (float)(lane + j) - 0.02f * (float)kt;
+  return;
+#endif
   const int kw = ddrl_tile_kw(kt, kp);
   const int cc = c < kw ? c : kw - 1;                  // clamp: columns >= kp are discarded by the caller
 #pragma unroll
@@ -227,6 +240,23 @@ struct OptCtx {
   float beta1, beta2, omb1, omb2, eps;
 };
 
+// 1 / (sqrt(v) + eps) on the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 instead of the ~25-instruction
+// IEEE expansions of sqrtf and '/': v >= 0 and the divisor is >= eps = 1e-8, well inside the normal
+// range, and a denormal v (where v_sqrt_f32 is inexact) is below eps^2 and changes nothing.
+__device__ __forceinline__ float adam_rdenom(float v, float eps) {
+  return __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
+}
+
+// Optimiser state other than the weights is touched once per update: streamed past the caches
+// (nontemporal) so that it does not evict the weights the eight passes re-read.
+#ifdef DDRL_EXP_NONT
+#define STREAM_LD(p) (*(const f32x4 *)(p))
+#define STREAM_ST(p, x) (*(f32x4 *)(p) = (x))
+#else
+#define STREAM_LD(p) __builtin_nontemporal_load((const f32x4 *)(p))
+#define STREAM_ST(p, x) __builtin_nontemporal_store((x), (f32x4 *)(p))
+#endif
+
 // Optimiser state of 4 consecutive parameters, requested before the products that produce their
 // gradient so the HBM latency hides behind the MFMAs.
 struct OptRegs { f32x4 w, m, v, wt, fisher, fhat, wstar; };
@@ -240,13 +270,13 @@ __device__ __forceinline__ void opt_load4(const OptCtx o, int i, OptRegs &r) {
   return;
 #endif
   r.w = *(const f32x4 *)(o.w + i);
-  r.m = *(const f32x4 *)(o.m + i);
-  r.v = *(const f32x4 *)(o.v + i);
+  r.m = STREAM_LD(o.m + i);
+  r.v = STREAM_LD(o.v + i);
   if (TGT) r.wt = *(const f32x4 *)(o.wt + i);
   if (EWC) {
-    r.fisher = *(const f32x4 *)(o.fisher + i);
-    r.fhat = *(const f32x4 *)(o.fhat + i);
-    r.wstar = *(const f32x4 *)(o.wstar + i);
+    r.fisher = STREAM_LD(o.fisher + i);
+    r.fhat = STREAM_LD(o.fhat + i);
+    r.wstar = STREAM_LD(o.wstar + i);
   }
 }
 
@@ -265,15 +295,15 @@ __device__ __forceinline__ void opt_step4(const OptCtx o, int i, f32x4 grad, con
   m = o.omb1 * grad + o.beta1 * r.m;
   v = o.omb2 * (grad * grad) + o.beta2 * r.v;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) w[e] -= o.lr_t * (m[e] / (sqrtf(v[e]) + o.eps));
+  for (int e = 0; e < 4; ++e) w[e] -= o.lr_t * (m[e] * adam_rdenom(v[e], o.eps));
   if (TGT) wt = o.tau * w + o.omtau * r.wt;
 #ifdef DDRL_EXP_NOOPTMEM
   ok = ok && (w[0] + wt[1] + m[2] + v[3] + (EWC ? f[0] : 0.f) == 12345.678f);
 #endif
   if (ok) {                                   // stores only: nothing waits on them
-    if (EWC) *(f32x4 *)(o.fisher + i) = f;
-    *(f32x4 *)(o.m + i) = m;
-    *(f32x4 *)(o.v + i) = v;
+    if (EWC) STREAM_ST(o.fisher + i, f);
+    STREAM_ST(o.m + i, m);
+    STREAM_ST(o.v + i, v);
     *(f32x4 *)(o.w + i) = w;
     if (TGT) *(f32x4 *)(o.wt + i) = wt;
   }
@@ -292,9 +322,37 @@ __device__ __forceinline__ void opt_step(const OptCtx o, int i, float grad) {
   const float v = o.omb2 * (grad * grad) + o.beta2 * o.v[i];
   o.m[i] = m;
   o.v[i] = v;
-  w -= o.lr_t * (m / (sqrtf(v) + o.eps));
+  w -= o.lr_t * (m * adam_rdenom(v, o.eps));
   o.w[i] = w;
   if (TGT) o.wt[i] = o.tau * w + o.omtau * o.wt[i];
+}
+
+// the same step with the state already in registers (requested at the start of the phase)
+struct OptRegs1 { float w, m, v, wt, fisher, fhat, wstar; };
+template <bool EWC, bool TGT>
+__device__ __forceinline__ void opt_load1(const OptCtx o, int i, OptRegs1 &r) {
+  r.w = o.w[i]; r.m = o.m[i]; r.v = o.v[i];
+  if (TGT) r.wt = o.wt[i];
+  if (EWC) { r.fisher = o.fisher[i]; r.fhat = o.fhat[i]; r.wstar = o.wstar[i]; }
+}
+template <bool EWC, bool TGT>
+__device__ __forceinline__ void opt_step1(const OptCtx o, int i, float grad, const OptRegs1 &r, bool ok) {
+  float w = r.w, f = 0.f;
+  if (EWC) {
+    f = r.fisher * o.fisher_beta + (grad * grad) * o.nsample;
+    grad += o.ewc_coef * r.fhat * (w - r.wstar);
+  }
+  grad += fmaxf(o.decay, 0.f) * w;
+  const float m = o.omb1 * grad + o.beta1 * r.m;
+  const float v = o.omb2 * (grad * grad) + o.beta2 * r.v;
+  w -= o.lr_t * (m * adam_rdenom(v, o.eps));
+  if (ok) {
+    if (EWC) o.fisher[i] = f;
+    o.m[i] = m;
+    o.v[i] = v;
+    o.w[i] = w;
+    if (TGT) o.wt[i] = o.tau * w + o.omtau * r.wt;
+  }
 }
 
 // dW[N x K] = dY^T X  (+ db = dY^T 1), each element handed to the optimiser straight from the MFMA
@@ -324,15 +382,29 @@ __device__ __forceinline__ f32x4 dw_tile(const float *__restrict__ dYs, int ldy,
   // clamped operand columns: the products they feed land in elements that are never stored
   const float *xa = Xs + (ak < kp ? ak : kp - 1) + 4 * g * ldx;
   const float *yb = dYs + (bn < N ? bn : N - 1) + 4 * g * ldy;
-  f32x4 acc = zero4();
+  f32x4 acc0 = zero4(), acc1 = zero4();     // two independent chains: 32- instead of 40-cycle issue
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc)
+  for (int mc = 0; mc < 4; mc += 2)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = mc * 16 + j;
-      acc = mfma16(xa[row * ldx], yb[row * ldy], acc);
+      acc0 = mfma16(xa[row * ldx], yb[row * ldy], acc0);
+      acc1 = mfma16(xa[(row + 16) * ldx], yb[(row + 16) * ldy], acc1);
     }
-  return acc;
+  return acc0 + acc1;
+}
+
+// db[n] = sum over the 64 rows of dY[:, n]: four interleaved partial sums so the LDS reads pipeline
+__device__ __forceinline__ float bias_grad(const float *__restrict__ dYs, int ldy, int n) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int row = 0; row < DDRL_MB; row += 4) {
+    s0 += dYs[row * ldy + n];
+    s1 += dYs[(row + 1) * ldy + n];
+    s2 += dYs[(row + 2) * ldy + n];
+    s3 += dYs[(row + 3) * ldy + n];
+  }
+  return (s0 + s1) + (s2 + s3);
 }
 
 template <bool EWC, bool TGT>
@@ -352,6 +424,12 @@ __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ld
   // stores are predicated.  The two-tile body is kept as a real loop (unrolling it
   // fully makes the scheduler hoist every tile's loads and spill); inside it the outstanding
   // loads are counted exactly (s_waitcnt vmcnt(N), not 0).
+  // the bias state first (every lane loads, clamped; N <= DDRL_MAXW <= 128 columns): its latency
+  // hides behind the whole tile loop
+  static_assert(DDRL_MAXW <= DDRL_NTHREADS, "one thread per bias");
+  OptRegs1 rb;
+  const int nb = tid < N ? tid : N - 1;
+  opt_load1<EWC, TGT>(o, offb + nb, rb);
   OptRegs r0, r1;
   bool ok0 = false, ok1 = false;
   int i0 = dw_elem(p0, total, KT, N, kp, offw, c, g, ok0), i1 = 0;
@@ -369,10 +447,6 @@ __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ld
       opt_step4<EWC, TGT>(o, i1, acc, r1, ok1);
     }
   }
-  // bias gradient: column sums of dY, ascending row order
-  for (int n = tid; n < N; n += DDRL_NTHREADS) {
-    float s = 0.f;
-    for (int row = 0; row < DDRL_MB; ++row) s += dYs[row * ldy + n];
-    opt_step<EWC, TGT>(o, offb + n, s);
-  }
+  // bias gradient: column sums of dY (waves whose lanes all sit beyond N skip the LDS reads)
+  if (wave * 64 < N) opt_step1<EWC, TGT>(o, offb + nb, bias_grad(dYs, ldy, nb), rb, tid < N);
 }

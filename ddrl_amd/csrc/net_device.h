@@ -18,11 +18,7 @@ __device__ __forceinline__ void bwd_dw_store(const float *__restrict__ dYs, int 
     const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p, total, KT, c, g);
     if (ok) *(f32x4 *)(gout + i) = acc;
   }
-  for (int n = tid; n < N; n += DDRL_NTHREADS) {
-    float s = 0.f;
-    for (int row = 0; row < DDRL_MB; ++row) s += dYs[row * ldy + n];
-    gout[offb + n] = s;
-  }
+  for (int n = tid; n < N; n += DDRL_NTHREADS) gout[offb + n] = bias_grad(dYs, ldy, n);
 }
 
 // a wave's LDS stores must have landed before the same wave's later loads of other lanes' values
