@@ -22,8 +22,27 @@ struct AgentState {
   std::mt19937 engine;
 };
 
+// DODevMLP's developmental schedule (common/include/nn/DODevMLP.hpp:76-214 exploit, :403-574
+// going_to_develop / develop / developIM / inform, :764-775 neutral_action): which controlled state /
+// action dimensions are open.  Host logic; the gates themselves act on the device (ddrl_pop_set_gates).
+struct DevCfg {
+  bool on = false, disable_st = false;
+  std::vector<long> st_control, ac_control, devpoints;
+  bool im = false, reset_learning_algo = false, informed = false;
+  int im_smooth = 0, im_window = 0;
+  std::vector<double> pd;                    // pd_controller_factor [nb_motors]
+};
+struct DevState {
+  std::vector<double> st_w, ac_w;            // the gate blobs, zero-initialised (DODevMLP.hpp:358-374)
+  std::vector<double> all_scores;
+  int last_episode_changed = 0;
+  unsigned im_index = 0;
+};
+
 struct ddrl_agents {
   ddrl_pop *pop = nullptr;
+  DevCfg dev;
+  std::vector<DevState> devst;
   int G = 0, S = 0, A = 0;
   double gamma = 0.99, noise = 0., noise2 = 0., noise3 = 0., reward_scale = 1.;
   int gaussian_policy = 0, decision_each = 1, force_more_update = 0;
@@ -116,6 +135,142 @@ extern "C" int ddrl_agents_destroy(ddrl_agents_t *h) {
   return DDRL_OK;
 }
 
+// DODevMLP::exploit (DODevMLP.hpp:76-214): the [devnn] keys, with the reference's consistency checks
+// as errors instead of exit(1).  Active when the ini has devnn.st_control.
+static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path) {
+  DevCfg &d = h->dev;
+  if (!ini.has("devnn.st_control")) return DDRL_OK;
+  try {
+    const bool st_scale = ini.get_bool("devnn.st_scale"), ac_scale = ini.get_bool("devnn.ac_scale");
+    const long st_prob = ini.get_long("devnn.st_probabilistic"), ac_prob = ini.get_long("devnn.ac_probabilistic");
+    d.disable_st = ini.get("devnn.st_control") == "None";                       // :132-136
+    if (!d.disable_st) d.st_control = ini.get_list("devnn.st_control");
+    d.ac_control = ini.get_list("devnn.ac_control");
+    const long heuristic = ini.has("devnn.heuristic") ? ini.get_long("devnn.heuristic") : 0;
+    if (heuristic == 0) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = 0 (gate weights learned by backpropagation) is not supported");
+    if (heuristic == 2) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = 2 needs probabilistic gates (st/ac_probabilistic = 0), which are not supported");
+    if (heuristic != 1) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = %ld unknown", heuristic);
+    if (st_prob != 1 || ac_prob != 1) return ddrl_fail(DDRL_EINVAL, "heuristic is 1 so probabilistic should be 1");     // :90-93
+    if (st_scale || ac_scale) return ddrl_fail(DDRL_EINVAL, "if not probabilistic then why scaling? of how much?");     // :192-195
+    if (ini.has("devnn.intrasec_motivation")) d.im = ini.get_bool("devnn.intrasec_motivation");
+    if (d.im) { d.im_smooth = (int)ini.get_long("devnn.im_smooth"); d.im_window = (int)ini.get_long("devnn.im_window"); }
+    d.devpoints = ini.get_list("devnn.heuristic_devpoints");
+    if (d.devpoints.size() != d.st_control.size() + d.ac_control.size())                 // :119-120
+      return ddrl_fail(DDRL_EINVAL, "heuristic_devpoints has %zu entries for %zu + %zu controlled dimensions", d.devpoints.size(),
+                       d.st_control.size(), d.ac_control.size());
+    if (ini.has("devnn.compute_diff_backward") && ini.get_bool("devnn.compute_diff_backward"))
+      return ddrl_fail(DDRL_EINVAL, "why do you compute diff if you don't use local solver?");                         // :207-210
+    if (ini.has("devnn.reset_learning_algo")) d.reset_learning_algo = ini.get_bool("devnn.reset_learning_algo");
+    if (ini.has("devnn.informed_sensorimotor_space")) d.informed = ini.get_bool("devnn.informed_sensorimotor_space");
+    if (d.informed) {
+      const std::string raw = ini.get("devnn.pd_controller_factor");
+      for (size_t pos = 0; pos <= raw.size();) {                                         // bib::to_array<double>: ':' separated
+        size_t e = raw.find(':', pos);
+        if (e == std::string::npos) e = raw.size();
+        if (e > pos) d.pd.push_back(std::stod(raw.substr(pos, e - pos)));
+        pos = e + 1;
+      }
+      if ((int)d.pd.size() != h->A) return ddrl_fail(DDRL_EINVAL, "wrong pd_controller_factor %zu", d.pd.size());       // :155-158
+    }
+  } catch (const std::exception &e) {
+    return ddrl_fail(DDRL_EIO, "%s: %s", ini_path, e.what());
+  }
+  if (d.im && (d.im_smooth < 1 || d.im_window < 0)) return ddrl_fail(DDRL_EINVAL, "devnn.im_smooth < 1 or im_window < 0");
+  if (d.st_control.empty() && !d.disable_st) return ddrl_fail(DDRL_EINVAL, "devnn.st_control: list the gated dimensions or None");
+  for (long c : d.st_control) if (c < 0 || c >= h->S) return ddrl_fail(DDRL_EINVAL, "devnn.st_control %ld outside 0..%d", c, h->S - 1);
+  for (long c : d.ac_control) if (c < 0 || c >= h->A) return ddrl_fail(DDRL_EINVAL, "devnn.ac_control %ld outside 0..%d", c, h->A - 1);
+  if (h->algo == 1 && d.reset_learning_algo) return ddrl_fail(DDRL_EINVAL, "NFAC cannot reset anything with DODevMLP");   // OfflineCaclaAg.hpp:199-203
+  if (h->algo == 2) return ddrl_fail(DDRL_EINVAL, "the developmental schedule is not supported for CMA-ES agents");
+  d.on = true;
+  h->devst.resize(h->G);
+  for (auto &st : h->devst) { st.st_w.assign(d.st_control.size(), 0.); st.ac_w.assign(d.ac_control.size(), 0.); }
+  return DDRL_OK;
+}
+
+// the deterministic Developmental layer (probabilist = 1): a controlled dimension whose weight is
+// below 0.5 is forced to 0, every other one passes
+static int push_gates(ddrl_agents *h) {
+  const DevCfg &d = h->dev;
+  std::vector<double> sg((size_t)h->G * h->S, 1.), ag((size_t)h->G * h->A, 1.);
+  for (int g = 0; g < h->G; ++g) {
+    for (size_t i = 0; i < d.st_control.size(); ++i) sg[(size_t)g * h->S + d.st_control[i]] = h->devst[g].st_w[i] < 0.5 ? 0. : 1.;
+    for (size_t i = 0; i < d.ac_control.size(); ++i) ag[(size_t)g * h->A + d.ac_control[i]] = h->devst[g].ac_w[i] < 0.5 ? 0. : 1.;
+  }
+  return ddrl_pop_set_gates(h->pop, sg.data(), ag.data());
+}
+
+// DODevMLP::update_DL_IM (:539-562) / still_something_to_develop (:517-537)
+static void update_dl_im(const DevCfg &d, DevState &st) {
+  for (size_t i = 0; i < d.devpoints.size(); ++i)
+    if ((unsigned long)d.devpoints[i] <= st.im_index) {
+      double &w = i < d.st_control.size() ? st.st_w[i] : st.ac_w[i - d.st_control.size()];
+      if (w < 0.5) w = 1.;
+    }
+  st.im_index++;
+}
+static bool still_something(const DevCfg &d, const DevState &st) {
+  for (size_t i = 0; i < d.devpoints.size(); ++i)
+    if ((unsigned long)d.devpoints[i] <= st.im_index + 1) {
+      const double w = i < d.st_control.size() ? st.st_w[i] : st.ac_w[i - d.st_control.size()];
+      if (w == 0.) return true;
+    }
+  return false;
+}
+
+// DODevMLP::inform (:566-574) for one agent: returns changed; *setup = ewc_setup() was called
+static bool dev_inform(const DevCfg &d, DevState &st, int episode, double score, bool *setup) {
+  *setup = false;
+  if (!d.im) {                                                         // develop (:420-470), heuristic 1
+    bool changed = false;
+    for (size_t i = 0; i < d.devpoints.size(); ++i)
+      if ((long)episode == d.devpoints[i]) {
+        (i < d.st_control.size() ? st.st_w[i] : st.ac_w[i - d.st_control.size()]) = 1.;
+        changed = true;
+      }
+    *setup = changed;                                                  // going_to_develop => ewc_setup() first (:422-424)
+    return changed;
+  }
+  if (episode == 0) { update_dl_im(d, st); return true; }               // developIM (:472-515)
+  const int ep = episode - st.last_episode_changed - 1;
+  st.all_scores.push_back(score);
+  double new_e = 0., new_ew = 0.;
+  for (int i = 0; i < d.im_smooth; ++i) {
+    new_e += ep - i < 0 ? -1e8 : st.all_scores[ep - i];                 // LOWER_REWARD (:7)
+    new_ew += ep - i - d.im_window < 0 ? -1e8 : st.all_scores[ep - i - d.im_window];
+  }
+  new_e *= 1. / (double)d.im_smooth;
+  new_ew *= 1. / (double)d.im_smooth;
+  const bool changed = new_e - new_ew <= 0. && ep >= d.im_smooth + d.im_window && still_something(d, st);
+  if (changed) {
+    *setup = true;
+    st.last_episode_changed += (int)st.all_scores.size();
+    update_dl_im(d, st);
+    st.all_scores.clear();
+  }
+  return changed;
+}
+
+// the learning branch of _start_episode (DeepQNAg.hpp:250-272, OfflineCaclaAg.hpp:225-234)
+static int dev_start_episode(ddrl_agents *h, const uint8_t *learning, const uint8_t *mask) {
+  const int G = h->G;
+  std::vector<uint8_t> changed(G, 0), setup(G, 0);
+  bool any_c = false, any_s = false;
+  for (int g = 0; g < G; ++g) {
+    if ((mask && !mask[g]) || !learning[g]) continue;
+    bool s = false;
+    if (dev_inform(h->dev, h->devst[g], h->ag[g].episode, h->ag[g].last_sum_weighted_reward, &s)) { changed[g] = 1; any_c = true; }
+    if (s) { setup[g] = 1; any_s = true; }
+  }
+  int rc;
+  if (any_s && h->pop->cfg.ewc >= 0. && (rc = ddrl_pop_ewc_setup_net(h->pop, DDRL_NET_ACTOR, setup.data()))) return rc;
+  if (!any_c) return DDRL_OK;
+  if ((rc = push_gates(h))) return rc;
+  if (h->dev.reset_learning_algo && h->algo == 0 && (rc = ddrl_pop_replay_clear(h->pop, changed.data()))) return rc;   // "reset learning catched"
+  if (h->pop->cfg.ewc >= 0. && h->pop->cfg.ewc_for_critic == 2 &&                                                      // ewc_force_constraint
+      (rc = ddrl_pop_ewc_setup_net(h->pop, DDRL_NET_CRITIC, changed.data()))) return rc;
+  return DDRL_OK;
+}
+
 // the keys both agents read around their nets: ARLAgent.hpp:142-159 + noise / gaussian_policy
 static int read_common(ddrl_agents *h, const char *ini_path, DdrlIni &ini) {
   std::string err;
@@ -178,6 +333,7 @@ extern "C" int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int n
   if ((rc = ddrl_ddpg_create(&cfg, seed, &h->pop))) return rc;
   h->force_more_update = cfg.force_more_update;
   init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
+  if ((rc = read_devnn(h.get(), ini, ini_path)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
   std::vector<uint32_t> rs(cfg.n_agents);
   for (int g = 0; g < cfg.n_agents; ++g) rs[g] = (uint32_t)(seed * 40503ull + 7919u * g + 17u);
   if ((rc = ddrl_pop_seed_replay(h->pop, rs.data()))) { ddrl_agents_destroy(h.release()); return rc; }
@@ -212,6 +368,7 @@ extern "C" int ddrl_agents_create_nfac(const char *ini_path, int n_agents, int n
   h->gamma = cfg.gamma;
   if ((rc = ddrl_nfac_create(&cfg, seed, &h->pop))) return rc;
   init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
+  if ((rc = read_devnn(h.get(), ini, ini_path)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
   *out = h.release();
   return DDRL_OK;
 }
@@ -359,6 +516,7 @@ extern "C" int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states, 
     s.step = 0;
   }
   if (h->algo == 2) return cmaes_start_instance(h, learning, mask);
+  if (h->dev.on) return dev_start_episode(h, learning, mask);
   return DDRL_OK;
 }
 
@@ -418,6 +576,9 @@ extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const floa
       memcpy(act, &h->pure[(size_t)g * A], A * sizeof(float));
       memcpy(&h->last_pure[(size_t)g * A], act, A * sizeof(float));
       if (learning[g] && h->algo != 2) explore(h, g, act);
+      if (h->dev.informed)                       // neutral_action (DODevMLP.hpp:764-775): closed action dimensions get the PD set point
+        for (size_t i = 0; i < h->dev.ac_control.size(); ++i)
+          if (h->devst[g].ac_w[i] < 0.5) act[h->dev.ac_control[i]] = (float)h->dev.pd[h->dev.ac_control[i]];
       memcpy(&h->last_action[(size_t)g * A], act, A * sizeof(float));
       memcpy(&h->last_state[(size_t)g * S], states + (size_t)g * S, S * sizeof(float));
       s.have_last = true;

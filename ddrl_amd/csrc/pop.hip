@@ -429,6 +429,20 @@ extern "C" int ddrl_pop_replay_load(ddrl_pop_t *h, int agent, int n, const float
   return DDRL_OK;
 }
 
+// trajectory.clear() (DeepQNAg.hpp:254-257) for every (masked) agent
+extern "C" int ddrl_pop_replay_clear(ddrl_pop_t *h, const uint8_t *mask) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  DDPG_ONLY(h);
+  int rc = set_device(h);
+  if (rc) return rc;
+  for (int g = 0; g < h->G; ++g)
+    if (!mask || mask[g]) { h->h_len[g] = 0; h->h_head[g] = 0; }
+  HIPCHK(hipMemcpyAsync(h->d_len, h->h_len.data(), h->G * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_head, h->h_head.data(), h->G * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
 extern "C" int ddrl_pop_replay_len(ddrl_pop_t *h, int32_t *len) {
   if (!h || !len) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   DDPG_ONLY(h);
@@ -563,6 +577,22 @@ extern "C" int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const
   return DDRL_OK;
 }
 
+extern "C" int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
+  std::vector<float> sg(G * S, 1.f), ag(G * A, 1.f);
+  if (h->gates_on) {
+    HIPCHK(hipMemcpyAsync(sg.data(), h->d_sgate, sg.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ag.data(), h->d_agate, ag.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  if (state_gate) for (size_t i = 0; i < G * S; ++i) state_gate[i] = sg[i];
+  if (action_gate) for (size_t i = 0; i < G * A; ++i) action_gate[i] = ag[i];
+  return DDRL_OK;
+}
+
 // ---- EWC life-cycle ----
 extern "C" int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score, const uint8_t *mask) {
   if (!h || !score) return ddrl_fail(DDRL_EINVAL, "NULL argument");
@@ -594,31 +624,48 @@ extern "C" int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score, co
   return DDRL_OK;
 }
 
+// DODevMLP::ewc_setup (DODevMLP.hpp:604-633) of one net for every (masked) agent with a best_param
+static int ewc_setup_one(ddrl_pop *h, TrainNet &t, const uint8_t *mask) {
+  if (!t.ewc.enabled) return DDRL_OK;
+  std::vector<uint8_t> flag(h->G, 0);
+  std::vector<float> nbr(h->G);
+  HIPCHK(hipMemcpyAsync(nbr.data(), t.st.fisher_nbr, h->G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  bool any = false;
+  for (int g = 0; g < h->G; ++g) {
+    if (mask && !mask[g]) continue;
+    if (!t.ewc.best_valid[g]) continue;             // DODevMLP.hpp:605: best_param == nullptr
+    // no gradient step since the last setup: the reference dereferences its dropped Fisher vector
+    // here (:620-621, fisher == nullptr after :629-630); the previous anchors are kept instead
+    if (!(nbr[g] > 0.f)) continue;
+    flag[g] = 1; any = true;
+    t.ewc.decay_mult[g] = 1.0;
+    t.ewc.best_score[g] = std::numeric_limits<double>::lowest();
+    t.ewc.live[g] = 1;
+  }
+  if (!any) return DDRL_OK;
+  int rc;
+  if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
+  HIPCHK(ewc_setup_launch(t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride(),
+                          h->d_flag, h->G, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return refresh_ewc_coef(h, t);
+}
+
 extern "C" int ddrl_pop_ewc_setup(ddrl_pop_t *h, const uint8_t *mask) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   int rc = set_device(h);
   if (rc) return rc;
-  for (int k = 0; k < 2; ++k) {
-    TrainNet &t = h->net[k];
-    if (!t.ewc.enabled) continue;
-    std::vector<uint8_t> flag(h->G, 0);
-    bool any = false;
-    for (int g = 0; g < h->G; ++g) {
-      if (mask && !mask[g]) continue;
-      if (!t.ewc.best_valid[g]) continue;             // DODevMLP.hpp:605: best_param == nullptr
-      flag[g] = 1; any = true;
-      t.ewc.decay_mult[g] = 1.0;
-      t.ewc.best_score[g] = std::numeric_limits<double>::lowest();
-      t.ewc.live[g] = 1;
-    }
-    if (!any) continue;
-    if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
-    HIPCHK(ewc_setup_launch(t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride(),
-                            h->d_flag, h->G, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if ((rc = refresh_ewc_coef(h, t))) return rc;
-  }
+  for (int k = 0; k < 2; ++k)
+    if ((rc = ewc_setup_one(h, h->net[k], mask))) return rc;
   return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_ewc_setup_net(ddrl_pop_t *h, int net, const uint8_t *mask) {
+  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  return ewc_setup_one(h, *train_net(h, net), mask);
 }
 
 extern "C" int ddrl_pop_ewc_decay_update(ddrl_pop_t *h, const uint8_t *mask) {

@@ -78,6 +78,9 @@ SYMBOLS = [
     ("ddrl_pop_ddpg_update", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ddpg_last", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("ddrl_pop_set_gates", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_get_gates", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_ewc_setup_net", _i, [_vp, _i, _vp]),
+    ("ddrl_pop_replay_clear", _i, [_vp, _vp]),
     ("ddrl_pop_update_best_param", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ewc_setup", _i, [_vp, _vp]),
     ("ddrl_pop_ewc_decay_update", _i, [_vp, _vp]),

@@ -120,6 +120,19 @@ class Population:
         ag = None if action_gate is None else np.ascontiguousarray(action_gate, np.float64).reshape(self.G, self.A)
         _l.check(self.L.ddrl_pop_set_gates(self.h, _p(sg), _p(ag)))
 
+    def gates(self):
+        sg, ag = np.empty((self.G, self.S)), np.empty((self.G, self.A))
+        _l.check(self.L.ddrl_pop_get_gates(self.h, _p(sg), _p(ag)))
+        return sg, ag
+
+    def ewc_setup_net(self, net, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_ewc_setup_net(self.h, net, _p(m)))
+
+    def replay_clear(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_replay_clear(self.h, _p(m)))
+
     def update_best_param(self, score, mask=None):
         s = np.ascontiguousarray(np.broadcast_to(np.asarray(score, np.float64), (self.G,)))
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

@@ -109,6 +109,8 @@ int ddrl_pop_replay_append(ddrl_pop_t *h, const float *s, const float *a, const 
 /* bulk load of n transitions into agent g's ring (benchmarks, resume): rows [n x (2S+A+2)] =
  * s, a, s2, r, goal */
 int ddrl_pop_replay_load(ddrl_pop_t *h, int agent, int n, const float *rows);
+/* trajectory.clear() ("reset learning catched", DeepQNAg.hpp:254-257) */
+int ddrl_pop_replay_clear(ddrl_pop_t *h, const uint8_t *mask);
 int ddrl_pop_replay_len(ddrl_pop_t *h, int32_t *len /* [G] */);
 
 /* MLP::computeOut on ann_testing (DeepQNAg.hpp:126; MLP.hpp:551-565) for all agents:
@@ -142,10 +144,15 @@ int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *q_target
  * state_gate [G x S], action_gate [G x A]; either may be NULL (= ones); both NULL = gates off.  The
  * schedule (DODevMLP::inform, :420-470) stays with the caller.  Applies to DDPG and NFAC handles. */
 int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const double *action_gate);
+/* the gates in force, [G x nb_sensors] / [G x nb_motors] (all ones when off); either may be NULL */
+int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate);
 
 /* EWC life-cycle (DODevMLP.hpp:604-758), per agent with mask[g] != 0 */
 int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score /* [G] */, const uint8_t *mask);
 int ddrl_pop_ewc_setup(ddrl_pop_t *h, const uint8_t *mask);
+/* the same for one net (DDRL_NET_ACTOR / DDRL_NET_CRITIC): the agents call ann->ewc_setup() at a
+ * development switch and qnn->ewc_setup() only with ewc_for_critic = 2 (DeepQNAg.hpp:253-261) */
+int ddrl_pop_ewc_setup_net(ddrl_pop_t *h, int net, const uint8_t *mask);
 int ddrl_pop_ewc_decay_update(ddrl_pop_t *h, const uint8_t *mask);
 int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost /* [G] */);
 /* fisher, fisher_hat (previous_fisher), wstar (best_param_previous_task): [G x n_params] */
@@ -173,6 +180,16 @@ int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int nb_sensors, 
 int ddrl_agents_create_nfac(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int max_trajectory,
                             int device, uint64_t seed, ddrl_agents_t **out);
 int ddrl_agents_destroy(ddrl_agents_t *h);
+/* DODevMLP's developmental schedule: when the ini has a [devnn] section with st_control, the DDPG and
+ * NFAC front ends read DODevMLP::exploit's keys (DODevMLP.hpp:76-214: st/ac_control, heuristic = 1 with
+ * heuristic_devpoints, intrasec_motivation + im_smooth / im_window, reset_learning_algo,
+ * informed_sensorimotor_space + pd_controller_factor; the reference's consistency checks are errors
+ * here), start with every controlled dimension closed and, at each learning start_episode, run
+ * inform(episode, last_sum_weighted_reward) per agent (:403-574): ewc_setup of the actor before a
+ * switch, the new gates on the device, the replay cleared with reset_learning_algo, the critic's
+ * ewc_setup with ewc_for_critic = 2 (DeepQNAg.hpp:250-272, OfflineCaclaAg.hpp:225-234); closed action
+ * dimensions return the PD set point (neutral_action, :764-775).  heuristic 0 (learned gates) and 2
+ * (probabilistic gates) are refused. */
 /* the population underneath (weights, Adam state, EWC life-cycle); owned by the front end */
 ddrl_pop_t *ddrl_agents_population(ddrl_agents_t *h);
 int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states /* [G x S] */, const uint8_t *learning,
