@@ -1,0 +1,118 @@
+// ddpg_device.h -- pieces shared by the fused DDPG update kernel (kernels_ddpg.hip, minibatches of up
+// to 64 rows in one workgroup) and the chunked one (kernels_ddpg_big.hip, larger minibatches).
+#pragma once
+#include "net_device.h"
+
+struct LdsMap {
+  float *hbase; int hstride; // hidden activation l (1..L-1) of the pass in flight lives at hbase + (l-1)*hstride
+  float *xc, *xa;            // critic input [s|a] tile, actor input s tile
+  float *topq, *topa;        // output tiles: q [64 x 4], actions [64 x ld(A)]
+  float *yv, *rv, *dn;       // TD target, reward, goal flag per row
+  float *nrew; int *nvalid;  // n-step return: discounted reward prefix and horizon per row
+};
+
+// gather one 64-row tile (B <= 64 rows are real: idx[0..B)) of the minibatch from the agent's replay ring (DeepQNAg.hpp:353-377,
+// nstep_return == 0).  next=true: s' into xa and xc[:, :S];  next=false: s into xa, [s|a] into xc,
+// reward / goal into rv / dn.
+__device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, int ldxc, int ldxa, int agent,
+                                            const int *__restrict__ idx, int B, int head, bool next,
+                                            const LdsMap &M, int tid) {
+  const float *rep = P.rep + (size_t)agent * P.cap * P.rowlen;
+  for (int e = tid; e < DDRL_MB * ldxc; e += DDRL_NTHREADS) {
+    const int row = e / ldxc, col = e - row * ldxc;
+    float v = 0.f;
+    if (row < B) {
+      int phys = head + idx[row] + (next && P.nstep > 0 ? M.nvalid[row] : 0);   // s' of the last valid step (:361-372)
+      if (phys >= P.cap) phys -= P.cap;
+      const float *rr = rep + (size_t)phys * P.rowlen;
+      if (next) { if (col < S) v = rr[S + A + col]; }
+      else if (col < S + A) v = rr[col];
+      // developmental gates on the state inputs of both nets and on the critic's action input
+      if (P.sgate && col < S) v *= P.sgate[(size_t)agent * S + col];
+      if (P.agate && col >= S && col < S + A) v *= P.agate[(size_t)agent * A + col - S];
+    }
+    M.xc[e] = v;
+    if (col < ldxa) M.xa[row * ldxa + col] = col < S ? v : 0.f;
+  }
+  if (!next)
+    for (int row = tid; row < DDRL_MB; row += DDRL_NTHREADS) {
+      float r = 0.f, d = 0.f;
+      if (row < B) {
+        int phys = head + idx[row];
+        if (phys >= P.cap) phys -= P.cap;
+        const float *rr = rep + (size_t)phys * P.rowlen;
+        r = rr[2 * S + A];
+        d = rr[2 * S + A + 1];
+      }
+      M.rv[row] = r;
+      M.dn[row] = d;
+    }
+}
+
+template <bool EWC>
+__device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &s, int stride,
+                                           int agent, float tau, float omtau, float nsample) {
+  OptCtx o;
+  const size_t off = (size_t)agent * stride;
+  o.w = s.w + off; o.m = s.m + off; o.v = s.v + off;
+  o.wt = s.wt + off;
+  o.fisher = EWC ? s.fisher + off : nullptr;
+  o.fhat = EWC ? s.fhat + off : nullptr;
+  o.wstar = EWC ? s.wstar + off : nullptr;
+  o.lr_t = s.lr_t[agent];     // bias-corrected rate of this update, computed in fp64 by the prep kernel
+  o.tau = tau; o.omtau = omtau;
+  o.decay = s.decay[agent];
+  o.ewc_coef = EWC ? s.ewc_coef[agent] : 0.f;
+  o.fisher_beta = P.fisher_beta;
+  o.nsample = nsample;
+  o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
+  return o;
+}
+
+
+// n-step horizon (DeepQNAg.hpp:360-373, 394-402) of the tile's rows: it stops before a transition
+// that reached the goal and at the end of the replay; rewards of steps [0, valid) are discounted
+__device__ __forceinline__ void nstep_horizon(const DdpgParams &P, int S, int A, int agent, const int *__restrict__ idx,
+                                              int B, int len, int head, float gamma, const LdsMap &M, int tid) {
+  if (tid < DDRL_MB) {
+    int valid = 0;
+    float acc = 0.f;
+    if (tid < B) {
+      const float *rep = P.rep + (size_t)agent * P.cap * P.rowlen;
+      const int i0 = idx[tid];
+      int last = i0;
+      for (int j = i0 + 1; j < i0 + P.nstep && j < len; ++j) {
+        const int ph = head + j >= P.cap ? head + j - P.cap : head + j;
+        if (rep[(size_t)ph * P.rowlen + 2 * S + A + 1] != 0.f) break;
+        last = j;
+      }
+      valid = last - i0;
+      float lg = 1.f;
+      for (int j = 0; j < valid; ++j) {
+        const int ph = head + i0 + j >= P.cap ? head + i0 + j - P.cap : head + i0 + j;
+        acc += rep[(size_t)ph * P.rowlen + 2 * S + A] * lg;
+        lg *= gamma;
+      }
+    }
+    M.nvalid[tid] = valid;
+    M.nrew[tid] = acc;
+  }
+  __syncthreads();
+}
+
+// carve LDS (same order as ddpg_update_lds_bytes)
+__device__ __forceinline__ LdsMap ddpg_carve(float *p, int La, int Lq, int ldh, int ldxc, int ldxa, int ldq, int lda) {
+  LdsMap M;
+  M.hbase = p; M.hstride = DDRL_MB * ldh;
+  p += ((La > Lq ? La : Lq) - 1) * M.hstride;
+  M.xc = p; p += DDRL_MB * ldxc;
+  M.xa = p; p += DDRL_MB * ldxa;
+  M.topq = p; p += DDRL_MB * ldq;
+  M.topa = p; p += DDRL_MB * lda;
+  M.yv = p; p += DDRL_MB;
+  M.rv = p; p += DDRL_MB;
+  M.dn = p; p += DDRL_MB;
+  M.nrew = p; p += DDRL_MB;
+  M.nvalid = (int *)p; p += DDRL_MB;
+  return M;
+}

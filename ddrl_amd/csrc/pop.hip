@@ -6,6 +6,7 @@
 extern "C" {
 hipError_t ddpg_update_launch(const DdpgParams *P, int force_generic, hipStream_t st);
 size_t ddpg_update_lds_bytes(const DdpgParams *P);
+hipError_t ddpg_update_big_launch(const DdpgParams *P, hipStream_t st);
 hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B, const uint8_t *mask,
                               int *idx_out, int draw, double beta1, double beta2, const float *lr_a,
                               const float *lr_q, const int *iter_a, const int *iter_q, float *lrt_a, float *lrt_q,
@@ -98,7 +99,7 @@ static int validate(const ddrl_ddpg_config *c) {
     if (c->hidden_unit_a[i] < 1 || c->hidden_unit_a[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_a[%d]=%d outside 1..%d (fused kernel limit)", i, c->hidden_unit_a[i], DDRL_MAXW);
   for (int i = 0; i < c->n_hidden_q; ++i)
     if (c->hidden_unit_q[i] < 1 || c->hidden_unit_q[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_q[%d]=%d outside 1..%d (fused kernel limit)", i, c->hidden_unit_q[i], DDRL_MAXW);
-  if (c->mini_batch_size < 1 || c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "mini_batch_size outside 1..%d", DDRL_MB);
+  if (c->mini_batch_size < 1 || c->mini_batch_size > DDRL_MAXB) return ddrl_fail(DDRL_EINVAL, "mini_batch_size outside 1..%d", DDRL_MAXB);
   if (c->replay_memory < c->mini_batch_size) return ddrl_fail(DDRL_EINVAL, "replay_memory < mini_batch_size");
   if (c->hidden_layer_type < 1 || c->hidden_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "hidden_layer_type not in (1,2,3)");
   if (c->actor_output_layer_type < 0 || c->actor_output_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "actor_output_layer_type not in 0..3");
@@ -145,6 +146,13 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   if ((rc = dalloc(h, &h->d_qt, (size_t)G * B))) return bail(rc);
   if ((rc = dalloc(h, &h->d_dact, (size_t)G * B * A))) return bail(rc);
   if ((rc = dalloc(h, &h->d_stamps, (size_t)G * 16))) return bail(rc);
+  float *d_gpart_a = nullptr, *d_gpart_q = nullptr, *d_loss_part = nullptr;
+  const int nchunks = (B + DDRL_MB - 1) / DDRL_MB;
+  if (nchunks > 1) {     // minibatches of more than one 64-row tile: per-chunk partial gradients (kernels_ddpg_big.hip)
+    if ((rc = dalloc(h, &d_gpart_a, (size_t)G * nchunks * h->net[0].nd.stride()))) return bail(rc);
+    if ((rc = dalloc(h, &d_gpart_q, (size_t)G * nchunks * h->net[1].nd.stride()))) return bail(rc);
+    if ((rc = dalloc(h, &d_loss_part, (size_t)G * nchunks))) return bail(rc);
+  }
   if ((rc = dalloc(h, &h->d_s, (size_t)G * S))) return bail(rc);
   if ((rc = dalloc(h, &h->d_s2, (size_t)G * S))) return bail(rc);
   if ((rc = dalloc(h, &h->d_a, (size_t)G * A))) return bail(rc);
@@ -208,6 +216,7 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   P.rep = h->d_rep; P.rep_len = h->d_len; P.rep_head = h->d_head; P.idx = h->d_idx;
   P.tau = h->d_tau; P.omtau = h->d_omtau; P.gamma = h->d_gamma;
   P.loss_out = h->d_loss; P.qt_out = h->d_qt; P.dact_out = h->d_dact;
+  P.maxchunks = nchunks; P.gpart_a = d_gpart_a; P.gpart_q = d_gpart_q; P.loss_part = d_loss_part;
   if (ddpg_update_lds_bytes(&P) > 160 * 1024) return bail(ddrl_fail(DDRL_EINVAL, "network too wide for the LDS-resident kernel (%zu bytes of LDS)", ddpg_update_lds_bytes(&P)));
   if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "sync failed"));
   *out = h;
@@ -534,7 +543,8 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
     h->ev_used++;
     HIPCHK(hipEventRecord(e0, h->stream));
   }
-  HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
+  if (h->P.maxchunks > 1) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
+  else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
   if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;

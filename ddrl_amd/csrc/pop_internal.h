@@ -9,6 +9,7 @@
 #define DDRL_NWAVES 8        // 512-thread workgroups: two waves per SIMD; 2 workgroups per CU => 4 waves per SIMD
 #endif
 #define DDRL_NTHREADS (DDRL_NWAVES * 64)
+#define DDRL_MAXB 4096       // largest minibatch (chunks of DDRL_MB rows, kernels_ddpg_big.hip)
 #define DDRL_MAXW 128        // max layer width handled by the fused (LDS-resident) kernels
 #define DDRL_MAXKC (DDRL_MAXW / 16)   // 16-deep k-chunks in the widest supported layer
 #define DDRL_MAXKT ((DDRL_MAXKC + DDRL_NWAVES - 1) / DDRL_NWAVES)   // dX column tiles per wave
@@ -124,6 +125,10 @@ struct DdpgParams {
   float *qt_out;            // [G x B] or null
   float *dact_out;          // [G x B x A] or null
   long long *stamps;        // [G x 16] s_memtime at phase boundaries (diagnostic), or null
+  // minibatches of more than 64 rows (kernels_ddpg_big.hip): per-chunk partial gradients and losses
+  int maxchunks;
+  float *gpart_a, *gpart_q; // [G x maxchunks x stride]
+  float *loss_part;         // [G x maxchunks]
 };
 
 // NFAC(lambda)-V kernels (kernels_nfac.hip)

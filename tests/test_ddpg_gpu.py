@@ -271,3 +271,38 @@ def test_forward_batch_all_nets(ora):
             out = pop.forward_batch(net, x)
             for g, ag in enumerate(agents):
                 assert rel_err(out[g], ag.nets[net].forward(x[g].astype(np.float64))) <= TOL, (n, net, g)
+
+
+# minibatches of more than one 64-row tile (kernels_ddpg_big.hip): the reference's own ddpg.ini / ddpg-cp.ini
+# use mini_batch_size = 512 with the "small" nets; 96 = one and a half tiles; 200 with EWC, gates off
+@pytest.mark.parametrize("B,hidden_a,hidden_q,kw", [
+    (512, (20,), (50, 7), dict()),
+    (96, (100, 100), (100, 100), dict(nstep_return=3, goal_prob=0.1)),
+    (200, (33, 17), (40, 21, 9), dict(momentum=1, decay_v=1e-3, inverting_grad=False)),
+])
+def test_large_minibatch_updates(ora, B, hidden_a, hidden_q, kw):
+    G = 3
+    pop, agents = make_pair(ora, G=G, B=B, hidden_a=hidden_a, hidden_q=hidden_q, wscale=0.1, sweep=True, seed=6, **kw)
+    rng = np.random.RandomState(8)
+    for it in range(3):
+        ws_prev, _ = sync_oracle_from_gpu(pop, agents)
+        idx = rng.randint(0, 1000, (G, B)).astype(np.int32) if it == 0 else None     # host indices, then the device's own draws
+        if idx is not None:
+            idx[:, :4] = [999, 998, 0, 1]
+        mask = np.array([1, 1, 0], np.uint8) if it == 2 else None
+        pop.update(idx, mask=mask)
+        last = pop.last()
+        for g, ag in enumerate(agents):
+            if mask is not None and not mask[g]:
+                assert np.array_equal(pop.weights(1)[g], ws_prev[1][g])
+                continue
+            loss, used = ag.update(None if idx is None else idx[g])
+            qt, dact = ag.last()
+            assert np.array_equal(used, last["idx"][g]), (it, g)
+            assert rel_err(last["q_targets"][g], qt) <= TOL
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            e = rel_err(last["dact"][g], dact)
+            assert e <= TOL or close_frac(last["dact"][g], dact, TOL, frac=0.99), e
+        if mask is None:
+            check_step(pop, agents, ws_prev, _hyper(agents), kw.get("momentum", 0), TOL, allow_kink=True)
+    assert list(pop.adam(0)[2]) == [3, 3, 2] and list(pop.adam(1)[2]) == [3, 3, 2]
