@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SIZES = {"small": ((20,), (50, 7)), "mid": ((100, 100), (100, 100))}
+SIZES = {"small": ((20,), (50, 7)), "mid": ((100, 100), (100, 100)), "large": ((400, 300), (400, 300))}
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table (spec; 6.29e12 measured copy rate)
 MFMA_F32_PEAK = 157.3e12   # FLOP/s dense fp32 matrix
 
@@ -197,7 +197,8 @@ def main():
                    "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "kernel": "ddpg_update_kernel", "kernel_avg_ms": kavg * 1e3, "launches": launches,
+                     "kernel": "ddpg_update_kernel" if max(ha + hq) <= 128 else "wide_* layer kernels + ddpg_apply_kernel (one update = 45 launches)",
+                     "kernel_avg_ms": kavg * 1e3, "launches": launches,
                      "algorithmic_bytes_per_agent_update": byts,
                      "mfma_f32_frac": flops * G / kavg / MFMA_F32_PEAK, "flops_per_agent_update": flops},
         "cpu_baseline": cpu,

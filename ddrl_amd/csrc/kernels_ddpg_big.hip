@@ -164,6 +164,10 @@ static hipError_t launch_apply(const DdpgParams *P, hipStream_t st) {
   return hipGetLastError();
 }
 
+extern "C" hipError_t ddpg_apply_launch(const DdpgParams *P, int net, hipStream_t st) {
+  return net == 0 ? launch_apply<0>(P, st) : launch_apply<1>(P, st);
+}
+
 extern "C" hipError_t ddpg_update_big_launch(const DdpgParams *P, hipStream_t st) {
   hipError_t e;
   if ((e = launch_chunks<0>(P, st)) != hipSuccess) return e;

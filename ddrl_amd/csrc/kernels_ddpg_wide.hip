@@ -1,0 +1,300 @@
+// kernels_ddpg_wide.hip -- the DDPG update for nets wider than the LDS-resident kernels take
+// (DDRL_MAXW = 128 < width <= DDRL_WIDE_MAXW; BASELINE.md "large": 400 x 300).  Same arithmetic and
+// the same order of operations as the fused kernel (kernels_ddpg.hip, DeepQNAg.hpp:343-466), but one
+// launch per layer operation: the 64-row activation tiles of an (agent, chunk) live in an HBM scratch
+// block (L2 resident between launches) instead of LDS, every launch spreads an agent's layer over
+// several workgroups (64-column blocks), and parameter gradients go through the per-chunk partials
+// and apply kernels of kernels_ddpg_big.hip.  Weights keep the tile-major layout, so weight
+// fragments are still contiguous 1-KiB wave loads.
+#include "ddpg_device.h"
+
+struct WideMap {
+  LdsMap M;              // the fused kernel's tiles, here pointers into the scratch block
+  float *ha, *hq, *da;   // hidden activations of the actor / critic pass, raw dQ/da [64 x ldpad(A)]
+  int hstride;
+};
+
+__host__ __device__ inline size_t wide_block_floats(const DdpgParams &P) {
+  const int A = P.a.d_[P.a.L_];
+  size_t f = (size_t)DDRL_MB * (P.ldxc + P.ldxa + P.q.ld_[P.q.L_] + P.a.ld_[P.a.L_] + 5 + ddrl_ldpad(A));
+  f += (size_t)(P.a.L_ - 1 + P.q.L_ - 1) * DDRL_MB * P.ldh;
+  return (f + 63) / 64 * 64;
+}
+
+__device__ __forceinline__ WideMap wide_map(const DdpgParams &P, int agent, int chunk) {
+  WideMap W;
+  float *p = P.wide + ((size_t)agent * P.maxchunks + chunk) * P.wide_stride;
+  const int A = P.a.d(P.a.L());
+  W.M.hbase = nullptr; W.M.hstride = 0;
+  W.M.xc = p; p += DDRL_MB * P.ldxc;
+  W.M.xa = p; p += DDRL_MB * P.ldxa;
+  W.M.topq = p; p += DDRL_MB * P.q.ld(P.q.L());
+  W.M.topa = p; p += DDRL_MB * P.a.ld(P.a.L());
+  W.M.yv = p; p += DDRL_MB;
+  W.M.rv = p; p += DDRL_MB;
+  W.M.dn = p; p += DDRL_MB;
+  W.M.nrew = p; p += DDRL_MB;
+  W.M.nvalid = (int *)p; p += DDRL_MB;
+  W.da = p; p += DDRL_MB * ddrl_ldpad(A);
+  W.hstride = DDRL_MB * P.ldh;
+  W.ha = p; p += (P.a.L() - 1) * W.hstride;
+  W.hq = p;
+  return W;
+}
+
+// the update guard of DeepQNAg.hpp:338 + mask + chunks beyond the minibatch
+__device__ __forceinline__ bool wide_skip(const DdpgParams &P, int agent, int chunk) {
+  if (P.mask && !P.mask[agent]) return true;
+  const int len = P.rep_len[agent];
+  return len < 250 || len < P.B || chunk * DDRL_MB >= P.B;
+}
+
+struct WideOp { int net, target, l, mode; };
+
+// where layer l of a net reads its input / writes its output inside the scratch block
+__device__ __forceinline__ void wide_io(const DdpgParams &P, const WideMap &W, int net, int l, const NetDesc &nd,
+                                        float *&in, int &ldi, float *&out, int &ldo) {
+  float *h = net ? W.hq : W.ha;
+  in = l == 0 ? (net ? W.M.xc : W.M.xa) : h + (l - 1) * W.hstride;
+  ldi = nd.ld(l);
+  const bool last = l == nd.L() - 1;
+  out = last ? (net ? W.M.topq : W.M.topa) : h + l * W.hstride;
+  ldo = nd.ld(l + 1);
+}
+
+// Y[64 x N] = act(X W^T + b): one 64-column block of outputs per workgroup, wave w owns rows 16w..16w+15
+__global__ void __launch_bounds__(256)
+wide_fwd_kernel(const DdpgParams P, const WideOp op) {
+  const int nb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
+  if (wide_skip(P, agent, chunk)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const NetDesc &nd = op.net ? P.q : P.a;
+  const NetState &st = op.net ? P.sq : P.sa;
+  const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
+  const float *wn = (op.target ? st.wt : st.w) + (size_t)agent * nd.stride();
+  const float *Wl = wn + nd.offw(l), *bias = wn + nd.offb(l);
+  const WideMap W = wide_map(P, agent, chunk);
+  float *X, *Y; int ldx, ldy;
+  wide_io(P, W, op.net, l, nd, X, ldx, Y, ldy);
+  const int act = l == nd.L() - 1 ? nd.out_act() : nd.hidden_act();
+  const float *xrow = X + (16 * wave + c) * ldx;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  const int KC = (kp + 15) >> 4;
+  for (int kc = 0; kc < KC; ++kc) {
+    const int kw = ddrl_tile_kw(kc, kp);
+    const bool in = kc * 16 + 4 * g < kp;
+    f32x4 av = *(const f32x4 *)(xrow + (in ? kc * 16 + 4 * g : kp - 4));
+    if (!in) av = zero4();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int nt = nb * 4 + t;
+      if (nt * 16 < N) {                        // uniform
+        const float *blk = Wl + ddrl_tile_base(nt, kc, kp) + c * kw;
+        const f32x4 bv = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t] = mfma16(av[e], bv[e], acc[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = (nb * 4 + t) * 16 + c;
+    if (n < ldy) {
+      const float bv = n < N ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y[(16 * wave + 4 * g + r) * ldy + n] = n < N ? act_fwd(act, acc[t][r] + bv) : 0.f;
+    }
+  }
+}
+
+// dX[64 x 64-column block] = dZ W for layer l.  mode 0: the block of H_{l-1} becomes dZ_{l-1} in
+// place (derivative taken from the activation's output, MLP.hpp:799-803).  mode 1 (layer 0 of the
+// critic): the action columns [S, S + A) go to W.da untouched.
+__global__ void __launch_bounds__(256)
+wide_dx_kernel(const DdpgParams P, const WideOp op) {
+  const int kb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
+  if (wide_skip(P, agent, chunk)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const NetDesc &nd = op.net ? P.q : P.a;
+  const NetState &st = op.net ? P.sq : P.sa;
+  const int l = op.l, kp = nd.kp(l), K = nd.d(l), N = nd.d(l + 1);
+  const float *Wl = st.w + (size_t)agent * nd.stride() + nd.offw(l);
+  const WideMap W = wide_map(P, agent, chunk);
+  float *in, *dZ; int ldi, ldz;
+  wide_io(P, W, op.net, l, nd, in, ldi, dZ, ldz);
+  const int n4 = ddrl_roundup(N, 4);
+  const float *zrow = dZ + (16 * wave + c) * ldz;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  const int NC = (N + 15) >> 4;
+  for (int nc = 0; nc < NC; ++nc) {
+    const bool inn = nc * 16 + 4 * g < n4;      // columns [N, n4) of dZ hold zeros
+    f32x4 av = *(const f32x4 *)(zrow + (inn ? nc * 16 + 4 * g : n4 - 4));
+    if (!inn) av = zero4();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kt = kb * 4 + t;
+      if (kt * 16 < kp) {                       // uniform
+        const int kw = ddrl_tile_kw(kt, kp);
+        const float *blk = Wl + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + (c < kw ? c : kw - 1);   // pad rows (n >= N) hold zeros
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], blk[j * kw], acc[t]);
+      }
+    }
+  }
+  const int S = P.S, A = P.A, ldda = ddrl_ldpad(A);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = (kb * 4 + t) * 16 + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wave + 4 * g + r;
+      if (op.mode == 0) {
+        if (col < K) in[row * ldi + col] = act_bwd(nd.hidden_act(), in[row * ldi + col], acc[t][r]);
+      } else if (col >= S && col < S + A) {
+        W.da[row * ldda + col - S] = acc[t][r];
+      }
+    }
+  }
+}
+
+// dW[64 n x 64 k block] = dZ^T X over the chunk's 64 rows (+ db for the k-block 0), written to the
+// chunk's partial-gradient image (same layout as the weights)
+__global__ void __launch_bounds__(256)
+wide_dw_kernel(const DdpgParams P, const WideOp op) {
+  __shared__ __align__(16) float sY[DDRL_MB * 68], sX[DDRL_MB * 68];
+  const int chunk = blockIdx.y, agent = blockIdx.z;
+  if (wide_skip(P, agent, chunk)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const NetDesc &nd = op.net ? P.q : P.a;
+  const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
+  const int KB = (kp + 63) >> 6;
+  const int nb = blockIdx.x / KB, kb = blockIdx.x - nb * KB;
+  const WideMap W = wide_map(P, agent, chunk);
+  float *X, *dZ; int ldx, ldz;
+  wide_io(P, W, op.net, l, nd, X, ldx, dZ, ldz);
+  for (int e = tid; e < DDRL_MB * 64; e += 256) {
+    const int row = e >> 6, col = e & 63;
+    sY[row * 68 + col] = nb * 64 + col < N ? dZ[row * ldz + nb * 64 + col] : 0.f;
+    sX[row * 68 + col] = kb * 64 + col < kp ? X[row * ldx + kb * 64 + col] : 0.f;
+  }
+  __syncthreads();
+  const int Nloc = N - nb * 64 < 64 ? N - nb * 64 : 64, kploc = kp - kb * 64 < 64 ? kp - kb * 64 : 64;
+  float *gout = (op.net ? P.gpart_q : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    const int p = wave * 4 + t;
+    const f32x4 acc = dw_tile(sY, 68, Nloc, sX, 68, kploc, p, 16, 4, c, g);
+    const int n = nb * 64 + (p >> 2) * 16 + c, k = kb * 64 + (p & 3) * 16 + 4 * g;
+    if (n < N && k < kp) *(f32x4 *)(gout + nd.offw(l) + ddrl_widx(n, k, kp)) = acc;
+  }
+  if (kb == 0 && tid < 64 && nb * 64 + tid < N) gout[nd.offb(l) + nb * 64 + tid] = bias_grad(sY, 68, tid);
+}
+
+// the element-wise steps between the layer launches, one workgroup per (chunk, agent)
+__global__ void __launch_bounds__(DDRL_NTHREADS)
+wide_step_kernel(const DdpgParams P, int step) {
+  const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x;
+  if (wide_skip(P, agent, chunk)) return;
+  const WideMap W = wide_map(P, agent, chunk);
+  const LdsMap &M = W.M;
+  const int S = P.S, A = P.A, B = P.B;
+  const int row0 = chunk * DDRL_MB;
+  const int nrows = B - row0 < DDRL_MB ? B - row0 : DDRL_MB;
+  const int ldxc = P.ldxc, ldxa = P.ldxa, ldq = P.q.ld(P.q.L()), lda = P.a.ld(P.a.L());
+  const int *idx = P.idx + (size_t)agent * B + row0;
+  const int len = P.rep_len[agent], head = P.rep_head[agent];
+  const float gamma = P.gamma[agent];
+  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  if (step == 0) {                       // s' tiles for the target pass
+    if (P.nstep > 0) nstep_horizon(P, S, A, agent, idx, nrows, len, head, gamma, M, tid);
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, true, M, tid);
+  } else if (step == 1) {                // actor output (gated) into the critic's action columns (gated again)
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+      const int row = e / A, col = e - row * A;
+      float a = M.topa[row * lda + col];
+      if (agate) {
+        a *= agate[col];
+        M.topa[row * lda + col] = a;
+        a *= agate[col];
+      }
+      M.xc[row * ldxc + S + col] = a;
+    }
+  } else if (step == 2) {                // [s|a] tiles + TD targets (DeepQNAg.hpp:386-405)
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
+    if (tid < DDRL_MB) {
+      const float qn = M.topq[tid * ldq];
+      const float y = M.dn[tid] != 0.f ? M.rv[tid] : (P.nstep > 0 ? M.nrew[tid] : M.rv[tid]) + gamma * qn;
+      M.yv[tid] = y;
+      if (P.qt_out && tid < nrows) P.qt_out[(size_t)agent * B + row0 + tid] = y;
+    }
+  } else if (step == 3) {                // EuclideanLoss over the whole minibatch
+    if (tid < DDRL_MB) {
+      const float df = tid < nrows ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
+      float sq = df * df;
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+      if (tid == 0) P.loss_part[(size_t)agent * P.maxchunks + chunk] = sq;
+      M.topq[tid * ldq] = df / (float)B;
+    }
+  } else if (step == 4) {                // DPG seed (:424-428), NOT / B
+    if (tid < DDRL_MB) M.topq[tid * ldq] = tid < nrows ? -1.0f : 0.f;
+  } else {                               // inverting gradients (:432-450) and the actor's output layer
+    const int ldda = ddrl_ldpad(A), out_act = P.a.out_act();
+    float *dact_out = P.dact_out ? P.dact_out + ((size_t)agent * B + row0) * A : nullptr;
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+      const int row = e / A, h = e - row * A;
+      float out = M.topa[row * lda + h];
+      const float gt = agate ? agate[h] : 1.f;
+      float diff = W.da[row * ldda + h] * gt;
+      if (P.inverting) {
+        if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
+        else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
+      }
+      if (dact_out && row < nrows) dact_out[row * A + h] = diff;
+      diff *= gt;
+      if (gt != 0.f) out /= gt;
+      M.topa[row * lda + h] = act_bwd(out_act, out, diff);
+    }
+  }
+}
+
+extern "C" size_t ddpg_wide_block_floats(const DdpgParams *P) { return wide_block_floats(*P); }
+extern "C" hipError_t ddpg_apply_launch(const DdpgParams *P, int net, hipStream_t st);
+
+#define WIDE_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+extern "C" hipError_t ddpg_update_wide_launch(const DdpgParams *Pp, hipStream_t st) {
+  const DdpgParams &P = *Pp;
+  const int C = (P.B + DDRL_MB - 1) / DDRL_MB, G = P.G;
+  auto step = [&](int s) { hipLaunchKernelGGL(wide_step_kernel, dim3(C, G), dim3(DDRL_NTHREADS), 0, st, P, s); };
+  auto fwd = [&](int net, int target) {
+    const NetDesc &nd = net ? P.q : P.a;
+    for (int l = 0; l < nd.L_; ++l) {
+      const WideOp op = {net, target, l, 0};
+      hipLaunchKernelGGL(wide_fwd_kernel, dim3((nd.ld_[l + 1] + 63) / 64, C, G), dim3(256), 0, st, P, op);
+    }
+  };
+  auto dx = [&](int net, int l, int mode) {
+    const NetDesc &nd = net ? P.q : P.a;
+    const WideOp op = {net, 0, l, mode};
+    hipLaunchKernelGGL(wide_dx_kernel, dim3((nd.kp_[l] + 63) / 64, C, G), dim3(256), 0, st, P, op);
+  };
+  auto dw = [&](int net, int l) {
+    const NetDesc &nd = net ? P.q : P.a;
+    const WideOp op = {net, 0, l, 0};
+    hipLaunchKernelGGL(wide_dw_kernel, dim3(((nd.d_[l + 1] + 63) / 64) * ((nd.kp_[l] + 63) / 64), C, G), dim3(256), 0, st, P, op);
+  };
+  hipError_t e;
+  // critic: y = r + gamma Q'(s', pi'(s')), then learn_batch (DeepQNAg.hpp:379-408)
+  step(0); fwd(0, 1); step(1); fwd(1, 1); step(2); fwd(1, 0); step(3);
+  for (int l = P.q.L_ - 1; l >= 0; --l) { dw(1, l); if (l > 0) dx(1, l, 0); }
+  WIDE_CHECK();
+  if ((e = ddpg_apply_launch(Pp, 1, st)) != hipSuccess) return e;
+  // actor: dQ/da through the NEW critic, inverting gradients, actor backward (:411-459)
+  fwd(0, 0); step(1); fwd(1, 0); step(4);
+  for (int l = P.q.L_ - 1; l >= 1; --l) dx(1, l, 0);
+  dx(1, 0, 1);
+  step(5);
+  for (int l = P.a.L_ - 1; l >= 0; --l) { dw(0, l); if (l > 0) dx(0, l, 0); }
+  WIDE_CHECK();
+  return ddpg_apply_launch(Pp, 0, st);
+}

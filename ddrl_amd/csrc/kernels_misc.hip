@@ -132,7 +132,7 @@ extern "C" __global__ void replay_append_kernel(float *__restrict__ rep, int *__
 extern "C" __global__ void __launch_bounds__(64)
 infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ states,
              float *__restrict__ actions, const float *__restrict__ in_gate, const float *__restrict__ out_gate) {
-  __shared__ __align__(16) float buf[2][DDRL_MAXW + 8];
+  __shared__ __align__(16) float buf[2][DDRL_WIDE_MAXW + 8];
   const int agent = blockIdx.x, lane = threadIdx.x;
   const float *wa = w + (size_t)agent * nd.stride();
   const int d0 = nd.d(0);

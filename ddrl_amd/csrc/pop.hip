@@ -7,6 +7,8 @@ extern "C" {
 hipError_t ddpg_update_launch(const DdpgParams *P, int force_generic, hipStream_t st);
 size_t ddpg_update_lds_bytes(const DdpgParams *P);
 hipError_t ddpg_update_big_launch(const DdpgParams *P, hipStream_t st);
+hipError_t ddpg_update_wide_launch(const DdpgParams *P, hipStream_t st);
+size_t ddpg_wide_block_floats(const DdpgParams *P);
 hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B, const uint8_t *mask,
                               int *idx_out, int draw, double beta1, double beta2, const float *lr_a,
                               const float *lr_q, const int *iter_a, const int *iter_q, float *lrt_a, float *lrt_q,
@@ -92,13 +94,13 @@ extern "C" int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *c) 
 static int validate(const ddrl_ddpg_config *c) {
   if (c->n_agents < 1) return ddrl_fail(DDRL_EINVAL, "n_agents < 1");
   if (c->nb_sensors < 1 || c->nb_motors < 1) return ddrl_fail(DDRL_EINVAL, "nb_sensors/nb_motors < 1");
-  if (c->nb_sensors + c->nb_motors > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "nb_sensors + nb_motors > %d", DDRL_MAXW);
+  if (c->nb_sensors + c->nb_motors > DDRL_WIDE_MAXW) return ddrl_fail(DDRL_EINVAL, "nb_sensors + nb_motors > %d", DDRL_WIDE_MAXW);
   if (c->n_hidden_a < 1 || c->n_hidden_a > DDRL_MAX_HIDDEN || c->n_hidden_q < 1 || c->n_hidden_q > DDRL_MAX_HIDDEN)
     return ddrl_fail(DDRL_EINVAL, "1..%d hidden layers supported", DDRL_MAX_HIDDEN);
   for (int i = 0; i < c->n_hidden_a; ++i)
-    if (c->hidden_unit_a[i] < 1 || c->hidden_unit_a[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_a[%d]=%d outside 1..%d (fused kernel limit)", i, c->hidden_unit_a[i], DDRL_MAXW);
+    if (c->hidden_unit_a[i] < 1 || c->hidden_unit_a[i] > DDRL_WIDE_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_a[%d]=%d outside 1..%d", i, c->hidden_unit_a[i], DDRL_WIDE_MAXW);
   for (int i = 0; i < c->n_hidden_q; ++i)
-    if (c->hidden_unit_q[i] < 1 || c->hidden_unit_q[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_q[%d]=%d outside 1..%d (fused kernel limit)", i, c->hidden_unit_q[i], DDRL_MAXW);
+    if (c->hidden_unit_q[i] < 1 || c->hidden_unit_q[i] > DDRL_WIDE_MAXW) return ddrl_fail(DDRL_EINVAL, "hidden_unit_q[%d]=%d outside 1..%d", i, c->hidden_unit_q[i], DDRL_WIDE_MAXW);
   if (c->mini_batch_size < 1 || c->mini_batch_size > DDRL_MAXB) return ddrl_fail(DDRL_EINVAL, "mini_batch_size outside 1..%d", DDRL_MAXB);
   if (c->replay_memory < c->mini_batch_size) return ddrl_fail(DDRL_EINVAL, "replay_memory < mini_batch_size");
   if (c->hidden_layer_type < 1 || c->hidden_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "hidden_layer_type not in (1,2,3)");
@@ -106,6 +108,24 @@ static int validate(const ddrl_ddpg_config *c) {
   if (c->momentum < 0 || c->momentum > 3) return ddrl_fail(DDRL_EINVAL, "momentum not in 0..3");
   if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
   if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
+  return DDRL_OK;
+}
+
+// per-chunk partial gradients (minibatches of more than one 64-row tile, and every wide update) and
+// the wide path's activation scratch; allocated once, when first needed
+static int chunk_buffers(ddrl_pop *h) {
+  DdpgParams &P = h->P;
+  const size_t G = h->G, C = P.maxchunks;
+  int rc;
+  if ((C > 1 || h->wide) && !P.gpart_a) {
+    if ((rc = dalloc(h, &P.gpart_a, G * C * h->net[0].nd.stride()))) return rc;
+    if ((rc = dalloc(h, &P.gpart_q, G * C * h->net[1].nd.stride()))) return rc;
+    if ((rc = dalloc(h, &P.loss_part, G * C))) return rc;
+  }
+  if (h->wide && !P.wide) {
+    P.wide_stride = ddpg_wide_block_floats(&P);
+    if ((rc = dalloc(h, &P.wide, G * C * P.wide_stride))) return rc;
+  }
   return DDRL_OK;
 }
 
@@ -146,13 +166,6 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   if ((rc = dalloc(h, &h->d_qt, (size_t)G * B))) return bail(rc);
   if ((rc = dalloc(h, &h->d_dact, (size_t)G * B * A))) return bail(rc);
   if ((rc = dalloc(h, &h->d_stamps, (size_t)G * 16))) return bail(rc);
-  float *d_gpart_a = nullptr, *d_gpart_q = nullptr, *d_loss_part = nullptr;
-  const int nchunks = (B + DDRL_MB - 1) / DDRL_MB;
-  if (nchunks > 1) {     // minibatches of more than one 64-row tile: per-chunk partial gradients (kernels_ddpg_big.hip)
-    if ((rc = dalloc(h, &d_gpart_a, (size_t)G * nchunks * h->net[0].nd.stride()))) return bail(rc);
-    if ((rc = dalloc(h, &d_gpart_q, (size_t)G * nchunks * h->net[1].nd.stride()))) return bail(rc);
-    if ((rc = dalloc(h, &d_loss_part, (size_t)G * nchunks))) return bail(rc);
-  }
   if ((rc = dalloc(h, &h->d_s, (size_t)G * S))) return bail(rc);
   if ((rc = dalloc(h, &h->d_s2, (size_t)G * S))) return bail(rc);
   if ((rc = dalloc(h, &h->d_a, (size_t)G * A))) return bail(rc);
@@ -216,8 +229,13 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   P.rep = h->d_rep; P.rep_len = h->d_len; P.rep_head = h->d_head; P.idx = h->d_idx;
   P.tau = h->d_tau; P.omtau = h->d_omtau; P.gamma = h->d_gamma;
   P.loss_out = h->d_loss; P.qt_out = h->d_qt; P.dact_out = h->d_dact;
-  P.maxchunks = nchunks; P.gpart_a = d_gpart_a; P.gpart_q = d_gpart_q; P.loss_part = d_loss_part;
-  if (ddpg_update_lds_bytes(&P) > 160 * 1024) return bail(ddrl_fail(DDRL_EINVAL, "network too wide for the LDS-resident kernel (%zu bytes of LDS)", ddpg_update_lds_bytes(&P)));
+  P.maxchunks = (B + DDRL_MB - 1) / DDRL_MB;
+  // nets wider than the LDS-resident kernels take go layer by layer (kernels_ddpg_wide.hip)
+  h->wide = S + A > DDRL_MAXW;
+  for (int k = 0; k < 2; ++k)
+    for (int l = 1; l < h->net[k].nd.L(); ++l) h->wide = h->wide || h->net[k].nd.d(l) > DDRL_MAXW;
+  if ((rc = chunk_buffers(h))) return bail(rc);
+  if (!h->wide && ddpg_update_lds_bytes(&P) > 160 * 1024) return bail(ddrl_fail(DDRL_EINVAL, "network too wide for the LDS-resident kernel (%zu bytes of LDS)", ddpg_update_lds_bytes(&P)));
   if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "sync failed"));
   *out = h;
   return DDRL_OK;
@@ -486,6 +504,8 @@ extern "C" int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions
 // MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579): n rows per agent through one net
 extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float *x, float *out) {
   if (!h || !x || !out || n < 1 || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  for (int l = 0; l < train_net(h, net)->nd.L(); ++l)
+    if (train_net(h, net)->nd.d(l) > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "forward_batch: layers wider than %d are not supported", DDRL_MAXW);
   int rc = set_device(h);
   if (rc) return rc;
   const TrainNet *t = train_net(h, net);
@@ -543,7 +563,8 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
     h->ev_used++;
     HIPCHK(hipEventRecord(e0, h->stream));
   }
-  if (h->P.maxchunks > 1) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
+  if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
+  else if (h->P.maxchunks > 1) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
   else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
   if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
@@ -773,5 +794,17 @@ extern "C" int ddrl_pop_debug_stamps(ddrl_pop_t *h, int enable, long long *out) 
 extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
   if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (std::string(key) == "force_generic") { h->force_generic = value != 0; return DDRL_OK; }
+  if (std::string(key) == "force_wide") {        // the layer-by-layer kernels on nets the fused kernel would take
+    DDPG_ONLY(h);
+    bool need = h->cfg.nb_sensors + h->cfg.nb_motors > DDRL_MAXW;
+    for (int k = 0; k < 2; ++k)
+      for (int l = 1; l < h->net[k].nd.L(); ++l) need = need || h->net[k].nd.d(l) > DDRL_MAXW;
+    h->wide = need || value != 0;
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = chunk_buffers(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DDRL_OK;
+  }
   return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);
 }

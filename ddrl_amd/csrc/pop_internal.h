@@ -10,6 +10,7 @@
 #endif
 #define DDRL_NTHREADS (DDRL_NWAVES * 64)
 #define DDRL_MAXB 4096       // largest minibatch (chunks of DDRL_MB rows, kernels_ddpg_big.hip)
+#define DDRL_WIDE_MAXW 1024  // widest layer of the layer-by-layer kernels (kernels_ddpg_wide.hip)
 #define DDRL_MAXW 128        // max layer width handled by the fused (LDS-resident) kernels
 #define DDRL_MAXKC (DDRL_MAXW / 16)   // 16-deep k-chunks in the widest supported layer
 #define DDRL_MAXKT ((DDRL_MAXKC + DDRL_NWAVES - 1) / DDRL_NWAVES)   // dX column tiles per wave
@@ -129,6 +130,9 @@ struct DdpgParams {
   int maxchunks;
   float *gpart_a, *gpart_q; // [G x maxchunks x stride]
   float *loss_part;         // [G x maxchunks]
+  // nets wider than DDRL_MAXW (kernels_ddpg_wide.hip): activation tiles in HBM, [G x maxchunks x wide_stride]
+  float *wide;
+  size_t wide_stride;
 };
 
 // NFAC(lambda)-V kernels (kernels_nfac.hip)

@@ -18,7 +18,7 @@ def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100
               replay_cap=2000, wscale=0.01, seed=0, hidden_act=1, actor_out_act=2, momentum=0,
               inverting_grad=True, decay_v=-1.0, sweep=True, ewc=-1.0, ewc_decay=-1.0,
               ewc_fisher_beta=0.999, ewc_for_critic=0, ewc_best_method=0, force_generic=False, nstep_return=0,
-              goal_prob=0.01):
+              goal_prob=0.01, force_wide=False):
     import ddrl_amd
     rng = np.random.RandomState(seed)
     cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=B,
@@ -29,6 +29,8 @@ def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100
                               ewc_for_critic=ewc_for_critic, ewc_best_param_method=ewc_best_method)
     pop = ddrl_amd.DdpgPopulation(cfg, init_seed=seed)
     pop.set_option("force_generic", int(force_generic))
+    if force_wide:
+        pop.set_option("force_wide", 1)
     if sweep:   # per-agent hyper-parameters drawn log-uniformly
         alpha_a = 10 ** rng.uniform(-5, -2, G); alpha_v = 10 ** rng.uniform(-5, -2, G)
         tau = 10 ** rng.uniform(-4, -1, G); gamma = rng.uniform(0.9, 0.999, G)

@@ -306,3 +306,37 @@ def test_large_minibatch_updates(ora, B, hidden_a, hidden_q, kw):
         if mask is None:
             check_step(pop, agents, ws_prev, _hyper(agents), kw.get("momentum", 0), TOL, allow_kink=True)
     assert list(pop.adam(0)[2]) == [3, 3, 2] and list(pop.adam(1)[2]) == [3, 3, 2]
+
+
+# the layer-by-layer kernels (kernels_ddpg_wide.hip): BASELINE.md "large" (400 x 300), a ragged wide pair with a
+# 1.5-tile minibatch and n-step targets, and -- forced -- the "mid" nets the fused kernel normally takes
+@pytest.mark.parametrize("B,hidden_a,hidden_q,kw", [
+    (64, (400, 300), (400, 300), dict()),
+    (96, (160, 200), (300,), dict(nstep_return=2, goal_prob=0.1, momentum=1, decay_v=1e-3)),
+    (64, (100, 100), (100, 100), dict(force_wide=True)),
+    (32, (20,), (50, 7), dict(force_wide=True, inverting_grad=False)),
+])
+def test_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, kw):
+    G = 2
+    pop, agents = make_pair(ora, G=G, B=B, hidden_a=hidden_a, hidden_q=hidden_q, wscale=0.05, sweep=True, seed=7, **kw)
+    rng = np.random.RandomState(3)
+    for it in range(3):
+        ws_prev, _ = sync_oracle_from_gpu(pop, agents)
+        idx = rng.randint(0, 1000, (G, B)).astype(np.int32) if it == 0 else None
+        pop.update(idx)
+        last = pop.last()
+        for g, ag in enumerate(agents):
+            loss, used = ag.update(None if idx is None else idx[g])
+            qt, dact = ag.last()
+            assert np.array_equal(used, last["idx"][g]), (it, g)
+            assert rel_err(last["q_targets"][g], qt) <= TOL
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            e = rel_err(last["dact"][g], dact)
+            assert e <= TOL or close_frac(last["dact"][g], dact, TOL, frac=0.99), e
+        check_step(pop, agents, ws_prev, _hyper(agents), kw.get("momentum", 0), TOL, allow_kink=True)
+    assert list(pop.adam(0)[2]) == [3, 3]
+    # inference through the wide nets
+    s = rng.uniform(-1, 1, (G, 18)).astype(np.float32)
+    a = pop.infer(s)
+    for g, ag in enumerate(agents):
+        assert np.max(np.abs(a[g] - ag.ann.forward(s[g].astype(np.float64))[0])) <= 1e-5
