@@ -117,7 +117,7 @@ static int chunk_buffers(ddrl_pop *h) {
   DdpgParams &P = h->P;
   const size_t G = h->G, C = P.maxchunks;
   int rc;
-  if ((C > 1 || h->wide) && !P.gpart_a) {
+  if ((C > 1 || h->wide || h->force_chunked) && !P.gpart_a) {
     if ((rc = dalloc(h, &P.gpart_a, G * C * h->net[0].nd.stride()))) return rc;
     if ((rc = dalloc(h, &P.gpart_q, G * C * h->net[1].nd.stride()))) return rc;
     if ((rc = dalloc(h, &P.loss_part, G * C))) return rc;
@@ -564,7 +564,7 @@ extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uin
     HIPCHK(hipEventRecord(e0, h->stream));
   }
   if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
-  else if (h->P.maxchunks > 1) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
+  else if (h->P.maxchunks > 1 || h->force_chunked) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
   else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
   if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
@@ -794,6 +794,15 @@ extern "C" int ddrl_pop_debug_stamps(ddrl_pop_t *h, int enable, long long *out) 
 extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
   if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (std::string(key) == "force_generic") { h->force_generic = value != 0; return DDRL_OK; }
+  if (std::string(key) == "force_chunked") {     // the gradient + apply kernels of the large-minibatch path on one-tile minibatches
+    DDPG_ONLY(h);
+    h->force_chunked = value != 0;
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = chunk_buffers(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DDRL_OK;
+  }
   if (std::string(key) == "force_wide") {        // the layer-by-layer kernels on nets the fused kernel would take
     DDPG_ONLY(h);
     bool need = h->cfg.nb_sensors + h->cfg.nb_motors > DDRL_MAXW;

@@ -64,6 +64,7 @@ struct ddrl_pop {
   // measurement
   bool profiling = false;
   int force_generic = 0;
+  bool force_chunked = false;
   bool wide = false;               // some layer is wider than DDRL_MAXW: layer-by-layer update kernels
   double beta1 = 0., beta2 = 0.999;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

@@ -10,6 +10,7 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ewc = 100.0 if (len(sys.argv) < 3 or sys.argv[2] == "ewc") else -1.0
 cfg = ddrl_amd.DdpgConfig(n_agents=G, replay_memory=2000, ewc=ewc, ewc_for_critic=1)
 pop = ddrl_amd.DdpgPopulation(cfg, init_seed=1)
+if os.environ.get("DDRL_CHUNKED"): pop.set_option("force_chunked", 1)
 rows = synth_rows(0, 2000, 18, 6)
 for g in range(G):
     pop.replay_load(g, rows)
