@@ -3,6 +3,13 @@
 #pragma once
 #include "net_device.h"
 
+#define DDRL_GATHER_TPR (DDRL_NTHREADS / DDRL_MB)   // threads per row in gather_tile
+// the thread that wrote rv[row] / dn[row] in gather_tile: it may read them back without a barrier
+__device__ __forceinline__ bool gather_owns_row(int tid, int &row) {
+  row = tid / DDRL_GATHER_TPR;
+  return tid - row * DDRL_GATHER_TPR == 0;
+}
+
 struct LdsMap {
   float *hbase; int hstride; // hidden activation l (1..L-1) of the pass in flight lives at hbase + (l-1)*hstride
   float *xc, *xa;            // critic input [s|a] tile, actor input s tile
@@ -17,36 +24,37 @@ struct LdsMap {
 __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, int ldxc, int ldxa, int agent,
                                             const int *__restrict__ idx, int B, int head, bool next,
                                             const LdsMap &M, int tid) {
+  // DDRL_NTHREADS / 64 threads per row, each with its own column residue: a thread reads idx[row] once
+  // and its row loads are independent of each other, so the whole gather costs two memory round trips
+  // (index, then row) instead of two per element
+  constexpr int TPR = DDRL_GATHER_TPR;
   const float *rep = P.rep + (size_t)agent * P.cap * P.rowlen;
-  for (int e = tid; e < DDRL_MB * ldxc; e += DDRL_NTHREADS) {
-    const int row = e / ldxc, col = e - row * ldxc;
+  const int row = tid / TPR, q = tid - row * TPR;
+  const bool live = row < B;
+  int phys = 0;
+  if (live) {
+    phys = head + idx[row] + (next && P.nstep > 0 ? M.nvalid[row] : 0);   // s' of the last valid step (:361-372)
+    if (phys >= P.cap) phys -= P.cap;
+  }
+  const float *rr = rep + (size_t)phys * P.rowlen;
+  const float *sg = P.sgate ? P.sgate + (size_t)agent * S : nullptr, *ag = P.agate ? P.agate + (size_t)agent * A : nullptr;
+#pragma unroll 8
+  for (int col = q; col < ldxc; col += TPR) {
     float v = 0.f;
-    if (row < B) {
-      int phys = head + idx[row] + (next && P.nstep > 0 ? M.nvalid[row] : 0);   // s' of the last valid step (:361-372)
-      if (phys >= P.cap) phys -= P.cap;
-      const float *rr = rep + (size_t)phys * P.rowlen;
+    if (live) {
       if (next) { if (col < S) v = rr[S + A + col]; }
       else if (col < S + A) v = rr[col];
       // developmental gates on the state inputs of both nets and on the critic's action input
-      if (P.sgate && col < S) v *= P.sgate[(size_t)agent * S + col];
-      if (P.agate && col >= S && col < S + A) v *= P.agate[(size_t)agent * A + col - S];
+      if (sg && col < S) v *= sg[col];
+      if (ag && col >= S && col < S + A) v *= ag[col - S];
     }
-    M.xc[e] = v;
+    M.xc[row * ldxc + col] = v;
     if (col < ldxa) M.xa[row * ldxa + col] = col < S ? v : 0.f;
   }
-  if (!next)
-    for (int row = tid; row < DDRL_MB; row += DDRL_NTHREADS) {
-      float r = 0.f, d = 0.f;
-      if (row < B) {
-        int phys = head + idx[row];
-        if (phys >= P.cap) phys -= P.cap;
-        const float *rr = rep + (size_t)phys * P.rowlen;
-        r = rr[2 * S + A];
-        d = rr[2 * S + A + 1];
-      }
-      M.rv[row] = r;
-      M.dn[row] = d;
-    }
+  if (!next && q == 0) {
+    M.rv[row] = live ? rr[2 * S + A] : 0.f;
+    M.dn[row] = live ? rr[2 * S + A + 1] : 0.f;
+  }
 }
 
 template <bool EWC>

@@ -20,9 +20,11 @@ ddpg_update_kernel(const DdpgParams P) {
   const int agent = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform, waits are counted exactly
-  if (P.mask && !P.mask[agent]) return;
+  // every per-agent scalar is requested before the first one is tested: one memory round trip, not four
+  const uint8_t live = P.mask ? P.mask[agent] : (uint8_t)1;
   const int len = P.rep_len[agent], head = P.rep_head[agent];
-  if (len < 250 || len < P.B) return;                      // DeepQNAg.hpp:338
+  const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
+  if (!live || len < 250 || len < P.B) return;             // DeepQNAg.hpp:338
   const auto &na = Pick<NA>::get(P.a);
   const auto &nq = Pick<NQ>::get(P.q);
   const int S = na.d(0), A = na.d(na.L()), B = P.B;
@@ -35,7 +37,6 @@ ddpg_update_kernel(const DdpgParams P) {
 #define STAMP(i) do { if (stamps && tid == 0) stamps[i] = clock64(); } while (0)
   STAMP(0);
   const int *idx = P.idx + (size_t)agent * B;
-  const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
   const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
   const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
   const float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
@@ -68,10 +69,11 @@ ddpg_update_kernel(const DdpgParams P) {
 
   // ---- TD targets (DeepQNAg.hpp:386-405, nstep_return == 0) ----
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
-  if (tid < DDRL_MB) {
-    const float qn = M.topq[tid * ldq];
+  int trow;
+  if (gather_owns_row(tid, trow)) {     // the thread that gathered the row's reward / goal flag
+    const float qn = M.topq[trow * ldq];
     // :388-403.  n-step: sum_{j<valid} gamma^j r_{t+j} + gamma * Q' (the reference's exponent, not gamma^valid)
-    M.yv[tid] = M.dn[tid] != 0.f ? M.rv[tid] : (P.nstep > 0 ? M.nrew[tid] : M.rv[tid]) + gamma * qn;
+    M.yv[trow] = M.dn[trow] != 0.f ? M.rv[trow] : (P.nstep > 0 ? M.nrew[trow] : M.rv[trow]) + gamma * qn;
   }
   __syncthreads();
   if (P.qt_out && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];

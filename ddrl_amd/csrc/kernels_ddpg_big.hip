@@ -55,9 +55,10 @@ ddpg_chunk_kernel(const DdpgParams P) {
     actions_to_critic();
     fwd_net(nq, nq.L(), w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);    // q' = qnn_target(s', a')
     gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
-    if (tid < DDRL_MB) {
-      const float qn = M.topq[tid * ldq];
-      M.yv[tid] = M.dn[tid] != 0.f ? M.rv[tid] : (P.nstep > 0 ? M.nrew[tid] : M.rv[tid]) + gamma * qn;
+    int trow;
+    if (gather_owns_row(tid, trow)) {
+      const float qn = M.topq[trow * ldq];
+      M.yv[trow] = M.dn[trow] != 0.f ? M.rv[trow] : (P.nstep > 0 ? M.nrew[trow] : M.rv[trow]) + gamma * qn;
     }
     __syncthreads();
     if (P.qt_out && tid < nrows) P.qt_out[(size_t)agent * B + row0 + tid] = M.yv[tid];

@@ -221,11 +221,12 @@ wide_step_kernel(const DdpgParams P, int step) {
     }
   } else if (step == 2) {                // [s|a] tiles + TD targets (DeepQNAg.hpp:386-405)
     gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
-    if (tid < DDRL_MB) {
-      const float qn = M.topq[tid * ldq];
-      const float y = M.dn[tid] != 0.f ? M.rv[tid] : (P.nstep > 0 ? M.nrew[tid] : M.rv[tid]) + gamma * qn;
-      M.yv[tid] = y;
-      if (P.qt_out && tid < nrows) P.qt_out[(size_t)agent * B + row0 + tid] = y;
+    int trow;
+    if (gather_owns_row(tid, trow)) {
+      const float qn = M.topq[trow * ldq];
+      const float y = M.dn[trow] != 0.f ? M.rv[trow] : (P.nstep > 0 ? M.nrew[trow] : M.rv[trow]) + gamma * qn;
+      M.yv[trow] = y;
+      if (P.qt_out && trow < nrows) P.qt_out[(size_t)agent * B + row0 + trow] = y;
     }
   } else if (step == 3) {                // EuclideanLoss over the whole minibatch
     if (tid < DDRL_MB) {

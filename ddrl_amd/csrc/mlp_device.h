@@ -125,22 +125,31 @@ __device__ __forceinline__ f32x4 row_tile(const AFrag &a, const BFrag &b, int kp
 }
 
 // Y[rows of this wave][N] = act(X W^T + b) for one layer.  Xs / Ys: LDS, 64 rows; columns
-// [N, ldy) of Ys are zeroed.  The next column tile's weight fragments are in flight while the
-// current tile is computed.
+// [N, ldy) of Ys are zeroed.  Three weight-fragment sets rotate: the loads for tile nt + 2 are issued
+// before tile nt is computed (one tile of MFMAs, ~900 cycles, does not cover an L2 round trip under
+// load).  The rotation also runs across the layer boundary: the last iteration requests tiles 0
+// and 1 of the NEXT layer (weights do not depend on activations) into b0 / b1, where the next call
+// expects them (`preloaded`), so a layer no longer starts with a cold wait.  nextW == nullptr: no
+// next layer.
+struct FwdNext { const float *W, *bias; int kp, N; };
+
 __device__ __forceinline__ void fwd_layer(const float *__restrict__ Xs, int ldx, int kp,
                                           const float *__restrict__ W, const float *__restrict__ bias,
-                                          int N, int act, float *__restrict__ Ys, int ldy, int wave, int lane) {
+                                          int N, int act, float *__restrict__ Ys, int ldy, int wave, int lane,
+                                          BFrag &b0, BFrag &b1, bool preloaded, const FwdNext nx) {
   const int g = lane >> 4, c = lane & 15;
   const int NT = (N + 15) >> 4;
   W = opaque(W);
   bias = opaque(bias);
+  const float *nW = nx.W ? opaque(nx.W) : nullptr, *nb = nx.W ? opaque(nx.bias) : nullptr;
+  const int nNT = (nx.N + 15) >> 4;
   AFrag a;
   load_afrag(Xs, ldx, kp, wave, lane, a);
-  // three fragment sets in rotation: the loads for tile nt + 2 are issued before tile nt is
-  // computed (one tile of MFMAs, ~900 cycles, does not cover an L2 round trip under load)
-  BFrag b0, b1, b2;
-  load_bfrag(W, bias, kp, N, 0, lane, b0);
-  if (1 < NT) load_bfrag(W, bias, kp, N, 1, lane, b1);
+  BFrag b2;
+  if (!preloaded) {
+    load_bfrag(W, bias, kp, N, 0, lane, b0);
+    if (1 < NT) load_bfrag(W, bias, kp, N, 1, lane, b1);
+  }
   float *yrow = Ys + (16 * wave + 4 * g) * ldy;
   auto store = [&](int nt, const f32x4 acc, const float bv) {
     const int n = nt * 16 + c;
@@ -152,16 +161,15 @@ __device__ __forceinline__ void fwd_layer(const float *__restrict__ Xs, int ldx,
   // a real loop: fully unrolled, the scheduler hoists every tile's weight loads and spills
 #pragma unroll 1
   for (int nt = 0; nt < NT; nt += 3) {
+    const bool tail = nt + 3 >= NT;            // last iteration: b0 / b1 are handed to the next layer
     if (nt + 2 < NT) load_bfrag(W, bias, kp, N, nt + 2, lane, b2);
     store(nt, row_tile(a, b0, kp), b0.bias);
-    if (nt + 1 < NT) {
-      if (nt + 3 < NT) load_bfrag(W, bias, kp, N, nt + 3, lane, b0);
-      store(nt + 1, row_tile(a, b1, kp), b1.bias);
-    }
-    if (nt + 2 < NT) {
-      if (nt + 4 < NT) load_bfrag(W, bias, kp, N, nt + 4, lane, b1);
-      store(nt + 2, row_tile(a, b2, kp), b2.bias);
-    }
+    if (nt + 3 < NT) load_bfrag(W, bias, kp, N, nt + 3, lane, b0);
+    else if (tail && nW) load_bfrag(nW, nb, nx.kp, nx.N, 0, lane, b0);
+    if (nt + 1 < NT) store(nt + 1, row_tile(a, b1, kp), b1.bias);
+    if (nt + 4 < NT) load_bfrag(W, bias, kp, N, nt + 4, lane, b1);
+    else if (tail && nW && 1 < nNT) load_bfrag(nW, nb, nx.kp, nx.N, 1, lane, b1);
+    if (nt + 2 < NT) store(nt + 2, row_tile(a, b2, kp), b2.bias);
   }
 }
 

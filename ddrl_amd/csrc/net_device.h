@@ -37,14 +37,20 @@ __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__rest
                                         int wave, int lane) {
   const float *in = X;
   int ldi = ldx;
+  BFrag b0, b1;       // weight fragments handed from layer to layer (requested one layer ahead)
 #pragma unroll
   for (int l = 0; l < nd.L(); ++l) {
     if (l < nl) {
       const bool last = l == nd.L() - 1;
       float *out = last ? top : hbase + l * hstride;
       const int ldo = last ? ldtop : nd.ld(l + 1);
+      FwdNext nx = {nullptr, nullptr, 4, 1};
+      if (l + 1 < nl) {
+        const int l1 = l + 1 < nd.L() ? l + 1 : l;     // (keeps the accessors in range when folded)
+        nx.W = w + nd.offw(l1); nx.bias = w + nd.offb(l1); nx.kp = nd.kp(l1); nx.N = nd.d(l1 + 1);
+      }
       fwd_layer(in, ldi, nd.kp(l), w + nd.offw(l), w + nd.offb(l), nd.d(l + 1),
-                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane);
+                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane, b0, b1, l > 0, nx);
       wave_lds_fence();
       in = out;
       ldi = ldo;
