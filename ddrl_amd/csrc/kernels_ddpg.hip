@@ -46,12 +46,16 @@ ddpg_update_kernel(const DdpgParams P) {
 
   // ---- n-step horizon (DeepQNAg.hpp:360-373, 394-402): the horizon stops before a transition that
   // reached the goal and at the end of the replay; rewards of steps [0, valid) are discounted ----
+  // the first weight fragments of the actor-target pass travel while the minibatch is gathered
+  FwdCarry cy;
+  const FwdNext no_next = {nullptr, nullptr, 4, 1};
+  fwd_request(fwd_first(na, w_at), lane, cy);
   if (P.nstep > 0) nstep_horizon(P, S, A, agent, idx, B, len, head, gamma, M, tid);
 
   // ---- a' = ann_target(s'), q' = qnn_target(s', a')  (DeepQNAg.hpp:379-383) ----
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);
   __syncthreads();
-  fwd_net(na, na.L(), w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);
+  fwd_net(na, na.L(), w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane, cy, true, fwd_first(nq, w_qt));
   for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
     const int row = e / A, col = e - row * A;
     float a = M.topa[row * lda + col];
@@ -64,7 +68,7 @@ ddpg_update_kernel(const DdpgParams P) {
   }
   __syncthreads();
   STAMP(1);
-  fwd_net(nq, nq.L(), w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
+  fwd_net(nq, nq.L(), w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane, cy, true, fwd_first(nq, w_q));
   STAMP(2);
 
   // ---- TD targets (DeepQNAg.hpp:386-405, nstep_return == 0) ----
@@ -80,7 +84,7 @@ ddpg_update_kernel(const DdpgParams P) {
   STAMP(3);
 
   // ---- critic update: qnn->learn_batch(s, a, y, 1)  (DeepQNAg.hpp:408; MLP.hpp:468-485) ----
-  fwd_net(nq, nq.L(), w_q, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
+  fwd_net(nq, nq.L(), w_q, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane, cy, true, no_next);
   if (tid < DDRL_MB) {
     // EuclideanLoss: loss = sum (q - y)^2 / (2B), dq = (q - y) / B
     const float df = tid < B ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
@@ -94,7 +98,8 @@ ddpg_update_kernel(const DdpgParams P) {
   auto none = [](int, int, float) {};
   {
     const OptCtx oq = make_opt<EWC_Q>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B);
-    bwd_net<DW_OPT, EWC_Q>(nq, w_q, oq, nullptr, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid);
+    bwd_net<DW_OPT, EWC_Q>(nq, w_q, oq, nullptr, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid,
+                           stamps ? stamps + 11 : nullptr);
   }
   STAMP(5);
 

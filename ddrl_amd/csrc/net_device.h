@@ -31,32 +31,57 @@ __device__ __forceinline__ void wave_lds_fence() {
 // forward through layers [0, nl) of a net; hidden activation l goes to hbase + (l-1)*hstride, the
 // output of the last InnerProduct (when nl == L) to top.  Row-parallel: every wave walks its own 16
 // rows through all layers; one workgroup barrier at the end publishes the results.
+// The weight fragments a forward pass starts with (tiles 0 and 1 of its first layer) can be requested
+// by the caller long before the pass -- at kernel start, or at the end of the previous pass -- and
+// travel in a FwdCarry; `after` names the first layer of the pass that follows (null: none).
+struct FwdCarry { BFrag b0, b1; };
+
+template <class ND>
+__device__ __forceinline__ FwdNext fwd_first(const ND nd, const float *__restrict__ w) {
+  FwdNext nx = {w + nd.offw(0), w + nd.offb(0), nd.kp(0), nd.d(1)};
+  return nx;
+}
+__device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry &cy) {
+  const float *W = opaque(nx.W), *bias = opaque(nx.bias);
+  load_bfrag(W, bias, nx.kp, nx.N, 0, lane, cy.b0);
+  if (16 < nx.N) load_bfrag(W, bias, nx.kp, nx.N, 1, lane, cy.b1);
+}
+
 template <class ND>
 __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__restrict__ w,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
-                                        int wave, int lane) {
+                                        int wave, int lane, FwdCarry &cy, bool preloaded, const FwdNext after) {
   const float *in = X;
   int ldi = ldx;
-  BFrag b0, b1;       // weight fragments handed from layer to layer (requested one layer ahead)
 #pragma unroll
   for (int l = 0; l < nd.L(); ++l) {
     if (l < nl) {
       const bool last = l == nd.L() - 1;
       float *out = last ? top : hbase + l * hstride;
       const int ldo = last ? ldtop : nd.ld(l + 1);
-      FwdNext nx = {nullptr, nullptr, 4, 1};
+      FwdNext nx = after;                                // the last layer of this pass hands over to the next pass
       if (l + 1 < nl) {
-        const int l1 = l + 1 < nd.L() ? l + 1 : l;     // (keeps the accessors in range when folded)
+        const int l1 = l + 1 < nd.L() ? l + 1 : l;       // (keeps the accessors in range when folded)
         nx.W = w + nd.offw(l1); nx.bias = w + nd.offb(l1); nx.kp = nd.kp(l1); nx.N = nd.d(l1 + 1);
       }
       fwd_layer(in, ldi, nd.kp(l), w + nd.offw(l), w + nd.offb(l), nd.d(l + 1),
-                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane, b0, b1, l > 0, nx);
+                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane, cy.b0, cy.b1, preloaded || l > 0, nx);
       wave_lds_fence();
       in = out;
       ldi = ldo;
     }
   }
   __syncthreads();
+}
+
+// a pass on its own: nothing requested ahead, nothing handed over
+template <class ND>
+__device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__restrict__ w,
+                                        const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
+                                        int wave, int lane) {
+  FwdCarry cy;
+  const FwdNext none = {nullptr, nullptr, 4, 1};
+  fwd_net(nd, nl, w, X, ldx, hbase, hstride, top, ldtop, wave, lane, cy, false, none);
 }
 
 // Backward through a whole net from dZ_L held in `top` (diff w.r.t. the last InnerProduct's
@@ -70,7 +95,8 @@ enum { DW_NONE = 0, DW_OPT = 1, DW_STORE = 2 };
 template <int TRAIN, bool EWC, class ND, class DX0>
 __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w, const OptCtx opt, float *gout,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
-                                        int c0, int nc, DX0 dx0_store, int wave, int lane, int tid) {
+                                        int c0, int nc, DX0 dx0_store, int wave, int lane, int tid,
+                                        long long *bst = nullptr) {   // bst: diagnostic s_memtime slots (dX done / dW done per layer)
   const int g = lane >> 4, c = lane & 15;
   float *dZ = top;
   int ldz = ldtop;
@@ -86,10 +112,12 @@ __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w
     int kt0 = 0, kt1 = (K + 15) >> 4;
     if (l == 0) { kt0 = c0 >> 4; kt1 = (c0 + nc + 15) >> 4; }
     if (need_dx) bwd_dx(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
+    if (bst && tid == 0 && ll < 2) bst[2 * ll] = clock64();
     if (TRAIN != DW_NONE) {
       __syncthreads();   // every wave's rows of dZ_l are final and every wave has read W_l
       if (TRAIN == DW_OPT) bwd_dw_opt<EWC, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
       else bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid);
+      if (bst && tid == 0 && ll < 2) bst[2 * ll + 1] = clock64();
       __syncthreads();   // every wave has read H_{l-1} before its rows are overwritten by dZ_{l-1}
     }
     if (need_dx) {

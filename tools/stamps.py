@@ -34,4 +34,6 @@ pop.set_profiling(True); pop.profile_read()
 for _ in range(20): pop.update()
 ms, n = pop.profile_read()
 print("kernel avg %.1f us over %d launches -> %.0f updates/s" % (ms / n * 1e3, n, G * n / ms * 1e3))
+bw = out[:, 11:15]
+print("critic bwd: dX3 %d | dW3+opt %d | dZ2 write+dX2 %d | dW2+opt %d | dZ1 write + dW1+opt %d" % tuple(np.median(x) for x in (bw[:, 0] - out[:, 4], bw[:, 1] - bw[:, 0], bw[:, 2] - bw[:, 1], bw[:, 3] - bw[:, 2], out[:, 5] - bw[:, 3])))
 print("span first start -> last end: %d cycles" % (out[:, 10].max() - out[:, 0].min()))
