@@ -80,20 +80,36 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
   const float *xrow = X + (16 * wave + c) * ldx;
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const int KC = (kp + 15) >> 4;
-  for (int kc = 0; kc < KC; ++kc) {
-    const int kw = ddrl_tile_kw(kc, kp);
-    const bool in = kc * 16 + 4 * g < kp;
-    f32x4 av = *(const f32x4 *)(xrow + (in ? kc * 16 + 4 * g : kp - 4));
-    if (!in) av = zero4();
+  // fragments of k-chunk kc + 1 are requested before chunk kc is multiplied (the weights come from HBM:
+  // without this every chunk paid a full round trip); two register sets, loop unrolled by two
+  struct Frag { f32x4 a, b[4]; };
+  auto load = [&](int kc, Frag &f) {
+    const int kcc = kc < KC ? kc : KC - 1;
+    const int kw = ddrl_tile_kw(kcc, kp);
+    const bool in = kcc * 16 + 4 * g < kp;
+    f.a = *(const f32x4 *)(xrow + (in ? kcc * 16 + 4 * g : kp - 4));
+    if (!in) f.a = zero4();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int nt = nb * 4 + t;
-      if (nt * 16 < N) {                        // uniform
-        const float *blk = Wl + ddrl_tile_base(nt, kc, kp) + c * kw;
-        const f32x4 bv = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
+      const int nt = nb * 4 + t < (N + 15) / 16 ? nb * 4 + t : (N + 15) / 16 - 1;     // clamped: tiles beyond N are discarded below
+      const float *blk = Wl + ddrl_tile_base(nt, kcc, kp) + c * kw;
+      f.b[t] = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
+    }
+  };
+  auto mul = [&](const Frag &f) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t] = mfma16(av[e], bv[e], acc[t]);
-      }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t] = mfma16(f.a[e], f.b[t][e], acc[t]);
+  };
+  Frag f0, f1;
+  load(0, f0);
+  for (int kc = 0; kc < KC; kc += 2) {
+    load(kc + 1, f1);
+    mul(f0);
+    if (kc + 1 < KC) {
+      load(kc + 2, f0);
+      mul(f1);
     }
   }
 #pragma unroll
@@ -125,20 +141,36 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
   const int n4 = ddrl_roundup(N, 4);
   const float *zrow = dZ + (16 * wave + c) * ldz;
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-  const int NC = (N + 15) >> 4;
-  for (int nc = 0; nc < NC; ++nc) {
-    const bool inn = nc * 16 + 4 * g < n4;      // columns [N, n4) of dZ hold zeros
-    f32x4 av = *(const f32x4 *)(zrow + (inn ? nc * 16 + 4 * g : n4 - 4));
-    if (!inn) av = zero4();
+  const int NC = (N + 15) >> 4, KT = (kp + 15) >> 4;
+  struct Frag { f32x4 a; float b[4][4]; };
+  auto load = [&](int nc, Frag &f) {          // chunk nc + 1 is in flight while chunk nc is multiplied
+    const int ncc = nc < NC ? nc : NC - 1;
+    const bool inn = ncc * 16 + 4 * g < n4;    // columns [N, n4) of dZ hold zeros
+    f.a = *(const f32x4 *)(zrow + (inn ? ncc * 16 + 4 * g : n4 - 4));
+    if (!inn) f.a = zero4();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int kt = kb * 4 + t;
-      if (kt * 16 < kp) {                       // uniform
-        const int kw = ddrl_tile_kw(kt, kp);
-        const float *blk = Wl + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + (c < kw ? c : kw - 1);   // pad rows (n >= N) hold zeros
+      const int kt = kb * 4 + t < KT ? kb * 4 + t : KT - 1;                            // clamped: discarded below
+      const int kw = ddrl_tile_kw(kt, kp);
+      const float *blk = Wl + ddrl_tile_base(ncc, kt, kp) + 4 * g * kw + (c < kw ? c : kw - 1);   // pad rows (n >= N) hold zeros
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], blk[j * kw], acc[t]);
-      }
+      for (int j = 0; j < 4; ++j) f.b[t][j] = blk[j * kw];
+    }
+  };
+  auto mul = [&](const Frag &f) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = mfma16(f.a[j], f.b[t][j], acc[t]);
+  };
+  Frag f0, f1;
+  load(0, f0);
+  for (int nc = 0; nc < NC; nc += 2) {
+    load(nc + 1, f1);
+    mul(f0);
+    if (nc + 1 < NC) {
+      load(nc + 2, f0);
+      mul(f1);
     }
   }
   const int S = P.S, A = P.A, ldda = ddrl_ldpad(A);

@@ -36,4 +36,7 @@ ms, n = pop.profile_read()
 print("kernel avg %.1f us over %d launches -> %.0f updates/s" % (ms / n * 1e3, n, G * n / ms * 1e3))
 bw = out[:, 11:15]
 print("critic bwd: dX3 %d | dW3+opt %d | dZ2 write+dX2 %d | dW2+opt %d | dZ1 write + dW1+opt %d" % tuple(np.median(x) for x in (bw[:, 0] - out[:, 4], bw[:, 1] - bw[:, 0], bw[:, 2] - bw[:, 1], bw[:, 3] - bw[:, 2], out[:, 5] - bw[:, 3])))
+for nm, sl in (("round 1 (agents < G/2)", slice(0, G // 2)), ("round 2", slice(G // 2, G))):
+    o = out[sl]
+    print(nm, "total %d | dW2+opt critic %d | fwd critic_t %d | start spread (p95-p5) %d" % (np.median(o[:, 10] - o[:, 0]), np.median(o[:, 14] - o[:, 13]), np.median(o[:, 2] - o[:, 1]), np.percentile(o[:, 0], 95) - np.percentile(o[:, 0], 5)))
 print("span first start -> last end: %d cycles" % (out[:, 10].max() - out[:, 0].min()))
