@@ -49,7 +49,7 @@ ddpg_update_kernel(const DdpgParams P) {
   // the first weight fragments of the actor-target pass travel while the minibatch is gathered
   FwdCarry cy;
   const FwdNext no_next = {nullptr, nullptr, 4, 1};
-  fwd_request(fwd_first(na, w_at), lane, cy);
+  if (!__is_same(NA, NetDesc)) fwd_request(fwd_first(na, w_at), lane, cy);
   if (P.nstep > 0) nstep_horizon(P, S, A, agent, idx, B, len, head, gamma, M, tid);
 
   // ---- a' = ann_target(s'), q' = qnn_target(s', a')  (DeepQNAg.hpp:379-383) ----

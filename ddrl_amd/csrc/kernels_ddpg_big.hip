@@ -10,7 +10,7 @@
 
 // PHASE 0: critic chunk.  PHASE 1: actor chunk.
 template <int PHASE>
-__global__ void __launch_bounds__(DDRL_NTHREADS)
+__global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 ddpg_chunk_kernel(const DdpgParams P) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void load_states(const float *__restrict__ traj, int 
 }
 
 // all_nextV = vnn(s'), all_V = vnn(s)   (OfflineCaclaAg.hpp:266,315 / :460-461)
-__global__ void __launch_bounds__(DDRL_NTHREADS)
+__global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 nfac_values_kernel(const NfacParams P) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y;
@@ -130,7 +130,7 @@ nfac_scan_kernel(const NfacParams P) {
 // d yhat = (yhat - y) / T).  MODE 1: actor, top diff = -(target - pi(s)) on the selected rows with
 // optional inverting gradient (OfflineCaclaAg.hpp:531-566), no 1/T.
 template <int MODE>
-__global__ void __launch_bounds__(DDRL_NTHREADS)
+__global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 nfac_grad_kernel(const NfacParams P) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y;
@@ -224,11 +224,11 @@ nfac_apply_kernel(const NfacParams P, int iter_add, int last) {
   const int i = (blockIdx.x * 256 + tid) * 4;
   if (i < nd.stride()) {
     OptRegs r;
-    opt_load4<EWC, false>(o, i, r);
+    opt_load4<EWC, false, false>(o, i, r);
     const float *gp = (MODE == 0 ? P.gpart_v : P.gpart_a) + (size_t)agent * P.maxchunks * nd.stride() + i;
     f32x4 g = *(const f32x4 *)gp;
     for (int c = 1; c < nch; ++c) g += *(const f32x4 *)(gp + (size_t)c * nd.stride());
-    opt_step4<EWC, false>(o, i, g, r, true);
+    opt_step4<EWC, false, false>(o, i, g, r, true);
   }
   if (blockIdx.x == 0 && tid == 0) {
     if (EWC) st.fisher_nbr[agent] = st.fisher_nbr[agent] * P.fisher_beta + nsample;   // DODevMLP.hpp:655
@@ -318,7 +318,7 @@ extern "C" hipError_t nfac_finish_launch(const NfacParams *P, int critic_steps, 
 // MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579) for every agent: n rows per agent through
 // one net.  X [G x n x d0], out [G x n x dL]; in_gate [G x d0] / out_gate [G x dL] or null.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(DDRL_NTHREADS)
+__global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out,
                    int n, int ldh, const float *__restrict__ sgate, int S, const float *__restrict__ agate, int A,
                    int gate_out) {

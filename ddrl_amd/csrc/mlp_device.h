@@ -255,15 +255,22 @@ __device__ __forceinline__ float adam_rdenom(float v, float eps) {
   return __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
 }
 
-// Optimiser state other than the weights is touched once per update: streamed past the caches
-// (nontemporal) so that it does not evict the weights the eight passes re-read.
-#ifdef DDRL_EXP_NONT
-#define STREAM_LD(p) (*(const f32x4 *)(p))
-#define STREAM_ST(p, x) (*(f32x4 *)(p) = (x))
-#else
-#define STREAM_LD(p) __builtin_nontemporal_load((const f32x4 *)(p))
-#define STREAM_ST(p, x) __builtin_nontemporal_store((x), (f32x4 *)(p))
+// NT: optimiser state other than the weights is touched once per update and is streamed past the
+// caches (nontemporal) so that it does not evict the weights the eight passes re-read -- the DDPG
+// population, 1.2 GB of state per launch.  NFAC runs ~100 full-batch Adam steps per update on a state
+// that fits the L2: there the ordinary cached accesses are the right ones (NT = false).
+template <bool NT> __device__ __forceinline__ f32x4 stream_ld(const float *p) {
+#ifndef DDRL_EXP_NONT
+  if (NT) return __builtin_nontemporal_load((const f32x4 *)p);
 #endif
+  return *(const f32x4 *)p;
+}
+template <bool NT> __device__ __forceinline__ void stream_st(float *p, f32x4 x) {
+#ifndef DDRL_EXP_NONT
+  if (NT) { __builtin_nontemporal_store(x, (f32x4 *)p); return; }
+#endif
+  *(f32x4 *)p = x;
+}
 
 // Optimiser state of 4 consecutive parameters, requested before the products that produce their
 // gradient so the HBM latency hides behind the MFMAs.
@@ -271,20 +278,20 @@ struct OptRegs { f32x4 w, m, v, wt, fisher, fhat, wstar; };
 
 // EWC: the net has Fisher / anchor arrays (DODevMLP.hpp:604-707).  TGT: the net has a target twin
 // that is soft-updated in the same pass (MLP.hpp:437-452).
-template <bool EWC, bool TGT>
+template <bool EWC, bool TGT, bool NT = true>
 __device__ __forceinline__ void opt_load4(const OptCtx o, int i, OptRegs &r) {
 #ifdef DDRL_EXP_NOOPTMEM
   r.w = r.m = r.v = r.wt = r.fisher = r.fhat = r.wstar = (f32x4){(float)i, 1.f, 2.f, 3.f};
   return;
 #endif
   r.w = *(const f32x4 *)(o.w + i);
-  r.m = STREAM_LD(o.m + i);
-  r.v = STREAM_LD(o.v + i);
+  r.m = stream_ld<NT>(o.m + i);
+  r.v = stream_ld<NT>(o.v + i);
   if (TGT) r.wt = *(const f32x4 *)(o.wt + i);
   if (EWC) {
-    r.fisher = STREAM_LD(o.fisher + i);
-    r.fhat = STREAM_LD(o.fhat + i);
-    r.wstar = STREAM_LD(o.wstar + i);
+    r.fisher = stream_ld<NT>(o.fisher + i);
+    r.fhat = stream_ld<NT>(o.fhat + i);
+    r.wstar = stream_ld<NT>(o.wstar + i);
   }
 }
 
@@ -292,7 +299,7 @@ __device__ __forceinline__ void opt_load4(const OptCtx o, int i, OptRegs &r) {
 // fhat / wstar are all-zero until the first ewc_setup), L2 decay (caffe SGDSolver::Regularize; decay
 // <= 0 = off), Adam (caffe AdamSolver::ComputeUpdateValue + Net::Update) and the target net's soft
 // update (MLP.hpp:449-450): one read and one write of each array per update, no branches.
-template <bool EWC, bool TGT>
+template <bool EWC, bool TGT, bool NT = true>
 __device__ __forceinline__ void opt_step4(const OptCtx o, int i, f32x4 grad, const OptRegs &r, bool ok) {
   f32x4 w = r.w, m, v, f, wt;
   if (EWC) {
@@ -309,9 +316,9 @@ __device__ __forceinline__ void opt_step4(const OptCtx o, int i, f32x4 grad, con
   ok = ok && (w[0] + wt[1] + m[2] + v[3] + (EWC ? f[0] : 0.f) == 12345.678f);
 #endif
   if (ok) {                                   // stores only: nothing waits on them
-    if (EWC) STREAM_ST(o.fisher + i, f);
-    STREAM_ST(o.m + i, m);
-    STREAM_ST(o.v + i, v);
+    if (EWC) stream_st<NT>(o.fisher + i, f);
+    stream_st<NT>(o.m + i, m);
+    stream_st<NT>(o.v + i, v);
     *(f32x4 *)(o.w + i) = w;
     if (TGT) *(f32x4 *)(o.wt + i) = wt;
   }

@@ -60,12 +60,16 @@ __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__rest
       float *out = last ? top : hbase + l * hstride;
       const int ldo = last ? ldtop : nd.ld(l + 1);
       FwdNext nx = after;                                // the last layer of this pass hands over to the next pass
-      if (l + 1 < nl) {
+      // run-time shapes keep all DDRL_MAXKC chunks of every fragment set allocated: there the hand-over
+      // costs more registers than it saves time (NFAC's 64-wide nets dropped to one wave per SIMD)
+      constexpr bool handover = !__is_same(ND, NetDesc);
+      if (!handover) nx.W = nullptr;
+      if (handover && l + 1 < nl) {
         const int l1 = l + 1 < nd.L() ? l + 1 : l;       // (keeps the accessors in range when folded)
         nx.W = w + nd.offw(l1); nx.bias = w + nd.offb(l1); nx.kp = nd.kp(l1); nx.N = nd.d(l1 + 1);
       }
       fwd_layer(in, ldi, nd.kp(l), w + nd.offw(l), w + nd.offb(l), nd.d(l + 1),
-                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane, cy.b0, cy.b1, preloaded || l > 0, nx);
+                last ? nd.out_act() : nd.hidden_act(), out, ldo, wave, lane, cy.b0, cy.b1, handover && (preloaded || l > 0), nx);
       wave_lds_fence();
       in = out;
       ldi = ldo;
