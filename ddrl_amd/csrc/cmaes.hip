@@ -788,11 +788,8 @@ static int rank_dev(ddrl_cmaes *h, const double *d_f, int n, int *d_index) {
   int p2 = 2;
   while (p2 < n) p2 <<= 1;
   const size_t lds = (size_t)p2 * (sizeof(unsigned long long) + sizeof(unsigned int));
-  static size_t configured = 0;
-  if (lds > 48 * 1024 && lds > configured) {
-    HIPCHK(hipFuncSetAttribute((const void *)cmaes_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  static LdsConfig configured;
+  HIPCHK(ddrl_set_lds(cmaes_rank_kernel, lds, configured));
   hipLaunchKernelGGL(cmaes_rank_kernel, dim3(1), dim3(1024), lds, h->stream, d_f, n, p2, d_index);
   HIPCHK(hipGetLastError());
   return DDRL_OK;

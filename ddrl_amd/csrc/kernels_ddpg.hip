@@ -177,13 +177,9 @@ typedef SNet<1, 0, 24, 50, 7, 1> SmallCritic;
 
 template <class NA, class NQ, bool EA, bool EQ>
 static hipError_t launch_t(const DdpgParams *P, size_t lds, hipStream_t st) {
-  static size_t configured = 0;
-  if (lds > 48 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)ddpg_update_kernel<NA, NQ, EA, EQ>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
+  static LdsConfig configured;
+  hipError_t e = ddrl_set_lds(ddpg_update_kernel<NA, NQ, EA, EQ>, lds, configured);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((ddpg_update_kernel<NA, NQ, EA, EQ>), dim3(P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
 }

@@ -143,13 +143,10 @@ extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P);
 
 template <int PHASE>
 static hipError_t launch_chunks(const DdpgParams *P, hipStream_t st) {
-  static size_t configured = 0;
+  static LdsConfig configured;
   const size_t lds = ddpg_update_lds_bytes(P);
-  if (lds > 48 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)ddpg_chunk_kernel<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
+  hipError_t e = ddrl_set_lds(ddpg_chunk_kernel<PHASE>, lds, configured);
+  if (e != hipSuccess) return e;
   const int nch = (P->B + DDRL_MB - 1) / DDRL_MB;
   hipLaunchKernelGGL(ddpg_chunk_kernel<PHASE>, dim3(nch, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();

@@ -252,33 +252,23 @@ __global__ void nfac_finish_kernel(const NfacParams P, int critic_steps, int act
 }
 
 // ---------------------------------------------------------------------------------------------
-template <class K>
-static hipError_t set_lds(K kernel, size_t lds, size_t &configured) {
-  if (lds > 48 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
-  return hipSuccess;
-}
-
 extern "C" size_t nfac_lds_need(const NfacParams *P) {
   return std::max(nfac_lds_bytes(P->a, P->ldh), nfac_lds_bytes(P->v, P->ldh));
 }
 
 extern "C" hipError_t nfac_values_launch(const NfacParams *P, int chunks, hipStream_t st) {
-  static size_t conf = 0;
+  static LdsConfig conf;
   const size_t lds = nfac_lds_bytes(P->v, P->ldh);
-  hipError_t e = set_lds(nfac_values_kernel, lds, conf);
+  hipError_t e = ddrl_set_lds(nfac_values_kernel, lds, conf);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(nfac_values_kernel, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
 }
 
 extern "C" hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen, hipStream_t st) {
-  static size_t conf0 = 0, conf1 = 0;
+  static LdsConfig conf0, conf1;
   const size_t lds = (size_t)std::max(maxlen, 1) * sizeof(float);
-  hipError_t e = mode == 0 ? set_lds(nfac_scan_kernel<0>, lds, conf0) : set_lds(nfac_scan_kernel<1>, lds, conf1);
+  hipError_t e = mode == 0 ? ddrl_set_lds(nfac_scan_kernel<0>, lds, conf0) : ddrl_set_lds(nfac_scan_kernel<1>, lds, conf1);
   if (e != hipSuccess) return e;
   if (mode == 0) hipLaunchKernelGGL(nfac_scan_kernel<0>, dim3(P->G), dim3(256), lds, st, *P);
   else hipLaunchKernelGGL(nfac_scan_kernel<1>, dim3(P->G), dim3(256), lds, st, *P);
@@ -286,9 +276,9 @@ extern "C" hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen
 }
 
 extern "C" hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, hipStream_t st) {
-  static size_t conf0 = 0, conf1 = 0;
+  static LdsConfig conf0, conf1;
   const size_t lds = nfac_lds_bytes(mode == 0 ? P->v : P->a, P->ldh);
-  hipError_t e = mode == 0 ? set_lds(nfac_grad_kernel<0>, lds, conf0) : set_lds(nfac_grad_kernel<1>, lds, conf1);
+  hipError_t e = mode == 0 ? ddrl_set_lds(nfac_grad_kernel<0>, lds, conf0) : ddrl_set_lds(nfac_grad_kernel<1>, lds, conf1);
   if (e != hipSuccess) return e;
   if (mode == 0) hipLaunchKernelGGL(nfac_grad_kernel<0>, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   else hipLaunchKernelGGL(nfac_grad_kernel<1>, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
@@ -352,11 +342,11 @@ net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *_
 
 extern "C" hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
                                          const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
-  static size_t conf = 0;
+  static LdsConfig conf;
   int ldh = 4;
   for (int l = 1; l < nd->L_; ++l) ldh = std::max(ldh, nd->ld_[l]);
   const size_t lds = nfac_lds_bytes(*nd, ldh);
-  hipError_t e = set_lds(net_forward_kernel, lds, conf);
+  hipError_t e = ddrl_set_lds(net_forward_kernel, lds, conf);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(net_forward_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out,
                      n, ldh, sgate, S, agate, A, gate_out);

@@ -159,3 +159,20 @@ struct NfacParams {
   float *loss_out;                // [G]
 };
 
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: the size already
+// configured is remembered per device (a handle per GPU may live in one process).  A concurrent
+// first launch from two threads at worst sets the attribute twice.
+struct LdsConfig { size_t bytes[64] = {}; };
+template <class K>
+static inline hipError_t ddrl_set_lds(K kernel, size_t lds, LdsConfig &cfg) {
+  if (lds <= 48 * 1024) return hipSuccess;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  if (lds > cfg.bytes[dev] || dev == 63) {
+    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    cfg.bytes[dev] = lds;
+  }
+  return hipSuccess;
+}

@@ -6,6 +6,9 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# not torch.cuda.is_available(): torch bundles its own HIP runtime, and initialising it AFTER libddrl_pop.so
+# (linked against /opt/rocm) was loaded leaves the latter without a device for the rest of the process
+HAVE_GPU = os.path.exists("/dev/kfd")
 
 
 def _declared():
@@ -80,13 +83,47 @@ ewc_for_critic=1
 
 
 def test_no_cpu_fallback():
-    import torch
-    if torch.cuda.is_available():
+    if HAVE_GPU:
         pytest.skip("GPU present")
     import ddrl_amd
     with pytest.raises(ddrl_amd.DdrlError) as e:
         ddrl_amd.DdpgPopulation(ddrl_amd.DdpgConfig(n_agents=2))
     assert "no HIP device" in str(e.value)
+    # every other way to a handle ends the same way: NFAC, policies only, CMA-ES, the agent front ends
+    with pytest.raises(ddrl_amd.DdrlError, match="no HIP device"):
+        ddrl_amd.NfacPopulation(ddrl_amd.NfacConfig(n_agents=2))
+    with pytest.raises(ddrl_amd.DdrlError, match="no HIP device"):
+        ddrl_amd.PolicyPopulation(3, 4, 2, (8,))
+    with pytest.raises(ddrl_amd.DdrlError):
+        ddrl_amd.Cmaes([0.0, 0.0], [1.0, 1.0], 1, 4)
+
+
+def test_agent_front_end_reads_ini_before_touching_the_gpu(tmp_path):
+    """host logic of the front ends that runs without a device: missing keys and [devnn] consistency
+    checks are reported from the ini (DODevMLP.hpp:90-210 exits there); a complete ini then fails at
+    the device, not before"""
+    import ddrl_amd
+    base = ("[agent]\ngamma=0.9\ndecision_each=1\nnoise=0.1\ngaussian_policy=1\nhidden_unit_q=8\nhidden_unit_a=8\n"
+            "mini_batch_size=16\nreplay_memory=300\ninverting_grad=false\nforce_more_update=0\ntau_soft_update=0.01\n"
+            "alpha_a=0.001\nalpha_v=0.002\ndecay_v=-1\nbatch_norm_critic=0\nbatch_norm_actor=0\n"
+            "actor_output_layer_type=2\nhidden_layer_type=1\ntest_net=false\nbn_adapt=false\nmomentum=0\nnstep_return=0\n")
+    p = tmp_path / "a.ini"
+    p.write_text(base.replace("decision_each=1\n", ""))
+    with pytest.raises(ddrl_amd.DdrlError, match="decision_each"):
+        ddrl_amd.DdpgAgents(str(p), 2, 4, 2)
+    p.write_text(base + "[devnn]\nst_scale=false\nac_scale=false\nst_probabilistic=0\nac_probabilistic=0\n"
+                        "st_control=1\nac_control=0\nheuristic=2\n")
+    if not HAVE_GPU:
+        with pytest.raises(ddrl_amd.DdrlError, match="no HIP device"):      # the population comes first, then [devnn]
+            ddrl_amd.DdpgAgents(str(p), 2, 4, 2)
+        p.write_text(base)
+        with pytest.raises(ddrl_amd.DdrlError, match="no HIP device"):
+            ddrl_amd.DdpgAgents(str(p), 2, 4, 2)
+    q = tmp_path / "c.ini"
+    q.write_text("[agent]\ngamma=0.9\ndecision_each=1\nhidden_unit_a=8\nactor_hidden_layer_type=1\n"
+                 "actor_output_layer_type=2\nbatch_norm=1\npopulation=8\ninitial_deviation=0.3\n")
+    with pytest.raises(ddrl_amd.DdrlError, match="batch_norm"):
+        ddrl_amd.CmaesAgents(str(q), 4, 2)
 
 
 def test_product_never_imports_oracle():
