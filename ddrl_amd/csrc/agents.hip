@@ -523,11 +523,7 @@ extern "C" int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states, 
 // one update round = 1 + force_more_update passes of the fupd loop (DeepQNAg.hpp:341); the
 // replay-size guard (:338) is applied per agent on the device
 static int update_round(ddrl_agents *h, const uint8_t *mask) {
-  for (int f = 0; f < 1 + h->force_more_update; ++f) {
-    int rc = ddrl_pop_ddpg_update(h->pop, nullptr, mask);
-    if (rc) return rc;
-  }
-  return DDRL_OK;
+  return ddrl_pop_ddpg_update_n(h->pop, 1 + h->force_more_update, nullptr, mask);   // one launch for the whole fupd loop
 }
 
 // ARLAgent::runf (ARLAgent.hpp:37-74) around DeepQNAg::_run (DeepQNAg.hpp:122-157) for every agent

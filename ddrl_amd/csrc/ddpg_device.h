@@ -59,7 +59,7 @@ __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, i
 
 template <bool EWC>
 __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &s, int stride,
-                                           int agent, float tau, float omtau, float nsample) {
+                                           int agent, float tau, float omtau, float nsample, int u = 0) {
   OptCtx o;
   const size_t off = (size_t)agent * stride;
   o.w = s.w + off; o.m = s.m + off; o.v = s.v + off;
@@ -67,7 +67,7 @@ __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &
   o.fisher = EWC ? s.fisher + off : nullptr;
   o.fhat = EWC ? s.fhat + off : nullptr;
   o.wstar = EWC ? s.wstar + off : nullptr;
-  o.lr_t = s.lr_t[agent];     // bias-corrected rate of this update, computed in fp64 by the prep kernel
+  o.lr_t = s.lr_t[(size_t)agent * P.nupd + u];     // bias-corrected rate of update u of this launch, computed in fp64 by the prep kernel
   o.tau = tau; o.omtau = omtau;
   o.decay = s.decay[agent];
   o.ewc_coef = EWC ? s.ewc_coef[agent] : 0.f;

@@ -13,37 +13,39 @@
 // constant; instantiated on NetDesc it is the generic kernel for any shape up to DDRL_MAXW.
 #include "ddpg_device.h"
 
+// one pass of the fupd loop (DeepQNAg.hpp:343-466) for one agent
 template <class NA, class NQ, bool EWC_A, bool EWC_Q>
-__global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU
-ddpg_update_kernel(const DdpgParams P) {
-  extern __shared__ __align__(16) float lds[];
-  const int agent = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform, waits are counted exactly
-  // every per-agent scalar is requested before the first one is tested: one memory round trip, not four
-  const uint8_t live = P.mask ? P.mask[agent] : (uint8_t)1;
-  const int len = P.rep_len[agent], head = P.rep_head[agent];
-  const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
-  if (!live || len < 250 || len < P.B) return;             // DeepQNAg.hpp:338
+__device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds, int agent, int u, int len, int head,
+                                                           float gamma, float tau, float omtau) {
+  const int tid0 = threadIdx.x;
   const auto &na = Pick<NA>::get(P.a);
   const auto &nq = Pick<NQ>::get(P.q);
   const int S = na.d(0), A = na.d(na.L()), B = P.B;
   const int ldxc = nq.ld(0), ldxa = na.ld(0);
   const int ldq = nq.ld(nq.L()), lda = na.ld(na.L());
-
+  const int tid = tid0, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform, waits are counted exactly
+  const int agent_u = agent;
   const LdsMap M = ddpg_carve(lds, na.L(), nq.L(), P.ldh, ldxc, ldxa, ldq, lda);
+#ifdef DDRL_EXP_STAGGER   // experiment: spread the first round's start times over DDRL_EXP_STAGGER cycles
+  if (agent_u < 512 && u == 0) {
+    const long long t0 = clock64();
+    const long long delay = (long long)(((unsigned)agent_u * 2654435761u) >> 8) % DDRL_EXP_STAGGER;
+    while (clock64() - t0 < delay) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 
-  long long *stamps = P.stamps ? P.stamps + (size_t)agent * 16 : nullptr;
+  long long *stamps = P.stamps ? P.stamps + (size_t)agent_u * 16 : nullptr;
 #define STAMP(i) do { if (stamps && tid == 0) stamps[i] = clock64(); } while (0)
-  STAMP(0);
-  const int *idx = P.idx + (size_t)agent * B;
-  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
-  const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
-  const float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
+  const float *agate = P.agate ? P.agate + (size_t)agent_u * A : nullptr;
+  const float *w_a = P.sa.w + (size_t)agent_u * na.stride(), *w_at = P.sa.wt + (size_t)agent_u * na.stride();
+  const float *w_q = P.sq.w + (size_t)agent_u * nq.stride(), *w_qt = P.sq.wt + (size_t)agent_u * nq.stride();
 #ifdef DDRL_EXP_HOTW      // experiment: every agent's passes read agent 0's weights (always cache-hot)
   w_a = P.sa.w; w_at = P.sa.wt; w_q = P.sq.w; w_qt = P.sq.wt;
 #endif
 
+  STAMP(0);
+  const int *idx = P.idx + ((size_t)agent_u * P.nupd + u) * B;
   // ---- n-step horizon (DeepQNAg.hpp:360-373, 394-402): the horizon stops before a transition that
   // reached the goal and at the end of the replay; rewards of steps [0, valid) are discounted ----
   // the first weight fragments of the actor-target pass travel while the minibatch is gathered
@@ -96,10 +98,14 @@ ddpg_update_kernel(const DdpgParams P) {
   __syncthreads();
   STAMP(4);
   auto none = [](int, int, float) {};
+  // compile-time shapes: the tiles from topq to the end of the allocation (topq after the top layer,
+  // topa, the per-row scalars and the tail the host adds, ddpg_update_lds_bytes) are dead during the
+  // optimiser loops below the top layer and park input-gradient accumulators there
+  float *park = __is_same(NQ, NetDesc) ? nullptr : M.topq;
   {
-    const OptCtx oq = make_opt<EWC_Q>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B);
+    const OptCtx oq = make_opt<EWC_Q>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B, u);
     bwd_net<DW_OPT, EWC_Q>(nq, w_q, oq, nullptr, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid,
-                           stamps ? stamps + 11 : nullptr);
+                           stamps ? stamps + 11 : nullptr, park);
   }
   STAMP(5);
 
@@ -148,8 +154,8 @@ ddpg_update_kernel(const DdpgParams P) {
   fwd_net(na, na.L() - 1, w_a, M.xa, ldxa, M.hbase, M.hstride, nullptr, 0, wave, lane);
   STAMP(9);
   {
-    const OptCtx oa = make_opt<EWC_A>(P, P.sa, na.stride(), agent, tau, omtau, (float)B);  // updateFisher(traj.size()) :456
-    bwd_net<DW_OPT, EWC_A>(na, w_a, oa, nullptr, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, 0, 0, none, wave, lane, tid);
+    const OptCtx oa = make_opt<EWC_A>(P, P.sa, na.stride(), agent, tau, omtau, (float)B, u);  // updateFisher(traj.size()) :456
+    bwd_net<DW_OPT, EWC_A>(na, w_a, oa, nullptr, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, 0, 0, none, wave, lane, tid, nullptr, park);
   }
   STAMP(10);
   if (tid == 0) {
@@ -160,11 +166,71 @@ ddpg_update_kernel(const DdpgParams P) {
   }
 }
 
+// One workgroup per (update, agent): blockIdx = u * G + agent.  P.nupd > 1 runs that many consecutive
+// passes of the fupd loop (DeepQNAg.hpp:341: 1 + force_more_update per stored transition) in ONE
+// launch.  An agent's updates depend only on each other, so nothing forces the population through
+// the grid-wide barrier of a kernel boundary between them: workgroup (u, agent) waits for P.upd_done[agent]
+// to reach u, which (u - 1, agent) publishes when its stores are out.  Workgroups are dispatched in
+// block order, (u - 1, agent) long before (u, agent) -- G - 1 workgroups lie between them -- so the wait
+// is rarely more than a glance, and it cannot deadlock: the lowest-numbered unfinished workgroup never
+// waits on an undispatched one.  It is bounded all the same: on expiry the workgroup gives up without
+// touching the agent and raises P.upd_error.  After the first pass the workgroups are out of phase, which
+// spreads the optimiser's HBM streaming over time (section 4.1 of DESIGN.md), and the tail of one pass
+// overlaps the head of the next.
+template <class NA, class NQ, bool EWC_A, bool EWC_Q>
+__global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU
+ddpg_update_kernel(const DdpgParams P) {
+  extern __shared__ __align__(16) float lds[];
+  const int u = P.nupd > 1 ? (int)blockIdx.x / P.G : 0;
+  const int agent = (int)blockIdx.x - u * P.G;
+  // every per-agent scalar is requested before the first one is tested: one memory round trip, not four
+  const uint8_t live = P.mask ? P.mask[agent] : (uint8_t)1;
+  const int len = P.rep_len[agent], head = P.rep_head[agent];
+  const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
+  if (!live || len < 250 || len < P.B) return;             // DeepQNAg.hpp:338
+  if (u > 0) {
+    // consumer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): relaxed polls by
+    // one lane, ONE agent-scope acquire (it invalidates this CU's L1), the wait for that invalidate,
+    // then the workgroup barrier, then plain loads
+    __shared__ int go;
+    if (threadIdx.x == 0) {
+      int ok = 0;
+      for (long long spin = 0; spin < (1ll << 22); ++spin) {              // ~ seconds: never reached in a healthy run
+        if (__hip_atomic_load(P.upd_done + agent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= u) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (!ok) __hip_atomic_store(P.upd_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      go = ok;
+    }
+    __syncthreads();
+    if (!go) return;
+  }
+  ddpg_update_once<NA, NQ, EWC_A, EWC_Q>(P, lds, agent, u, len, head, gamma, tau, omtau);
+  if (P.nupd > 1) {
+    // producer side: every storing wave waits for its stores, the barrier, then ONE lane's agent-scope
+    // release (writes the XCD L2's dirty lines back), its wait, and only then the counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(P.upd_done + agent, u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // host-visible LDS sizing, same carve order as the kernel
 extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P) {
   size_t f = 0;
   { const int nh = (P->a.L_ > P->q.L_ ? P->a.L_ : P->q.L_) - 1; f += (size_t)nh * DDRL_MB * P->ldh; }
-  f += (size_t)DDRL_MB * (P->ldxc + P->ldxa + P->q.ld_[P->q.L_] + P->a.ld_[P->a.L_] + 5);
+  f += (size_t)DDRL_MB * (P->ldxc + P->ldxa);
+  // from topq on: the output tiles and per-row scalars, at least the park area of bwd_net
+  // (DDRL_PARK_TILES KiB per wave; used by the compile-time instantiations)
+  const size_t tail = (size_t)DDRL_MB * (P->q.ld_[P->q.L_] + P->a.ld_[P->a.L_] + 5);
+  const size_t parkf = (size_t)DDRL_NWAVES * DDRL_PARK_TILES * 256;
+  f += tail > parkf ? tail : parkf;
   return f * sizeof(float);
 }
 
@@ -180,7 +246,7 @@ static hipError_t launch_t(const DdpgParams *P, size_t lds, hipStream_t st) {
   static LdsConfig configured;
   hipError_t e = ddrl_set_lds(ddpg_update_kernel<NA, NQ, EA, EQ>, lds, configured);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((ddpg_update_kernel<NA, NQ, EA, EQ>), dim3(P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  hipLaunchKernelGGL((ddpg_update_kernel<NA, NQ, EA, EQ>), dim3(P->G * (P->nupd > 1 ? P->nupd : 1)), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
 }
 

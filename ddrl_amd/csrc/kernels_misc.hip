@@ -24,29 +24,34 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // digits in fp32 at small t.  draw == 0: indices come from the host, only the step sizes are made.
 extern "C" __global__ void __launch_bounds__(64)
 replay_draw_kernel(uint32_t *__restrict__ mt, int *__restrict__ pos, const int *__restrict__ rep_len,
-                   int B, int min_len, const uint8_t *__restrict__ mask, int *__restrict__ idx_out, int draw,
+                   int B, int nupd, int min_len, const uint8_t *__restrict__ mask, int *__restrict__ idx_out, int draw,
                    double beta1, double beta2, const float *__restrict__ lr_a, const float *__restrict__ lr_q,
                    const int *__restrict__ iter_a, const int *__restrict__ iter_q,
-                   float *__restrict__ lrt_a, float *__restrict__ lrt_q) {
+                   float *__restrict__ lrt_a, float *__restrict__ lrt_q, int *__restrict__ upd_done) {
   __shared__ uint32_t st[624];
   const int agent = blockIdx.x, lane = threadIdx.x;
+  if (upd_done && lane == 0) upd_done[agent] = 0;       // progress counter of the coming launch (ddpg_update_kernel)
   if (mask && !mask[agent]) return;
   const uint32_t n = (uint32_t)rep_len[agent];
   if ((int)n < min_len || (int)n < B) return;       // the guard of DeepQNAg.hpp:338: no draw consumed
-  if (lane < 2) {
-    const int t = (lane ? iter_q : iter_a)[agent] + 1;
+  // nupd consecutive updates in one launch (the fupd loop, DeepQNAg.hpp:341): step sizes for
+  // t = iter + 1 .. iter + nupd, and nupd * B indices drawn back to back like nupd calls would
+  for (int j = lane; j < 2 * nupd; j += 64) {
+    const int q = j & 1, u = j >> 1;
+    const int t = (q ? iter_q : iter_a)[agent] + 1 + u;
     const double corr = sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
-    (lane ? lrt_q : lrt_a)[agent] = (float)((double)(lane ? lr_q : lr_a)[agent] * corr);
+    (q ? lrt_q : lrt_a)[(size_t)agent * nupd + u] = (float)((double)(q ? lr_q : lr_a)[agent] * corr);
   }
   if (!draw) return;
+  const int count = B * nupd;
   uint32_t *gst = mt + (size_t)agent * 624;
   for (int i = lane; i < 624; i += 64) st[i] = gst[i];
   int p = pos[agent];
   __syncthreads();
   const uint32_t thresh = (uint32_t)(0u - n) % n;
-  int *out = idx_out + (size_t)agent * B;
+  int *out = idx_out + (size_t)agent * count;
   int drawn = 0;
-  while (drawn < B) {
+  while (drawn < count) {
     if (p >= 624) {
       for (int b = 0; b < 624; b += 64) {
         const int i = b + lane;
@@ -62,7 +67,7 @@ replay_draw_kernel(uint32_t *__restrict__ mt, int *__restrict__ pos, const int *
       p = 0;
     }
     int chunk = 624 - p;
-    if (chunk > B - drawn) chunk = B - drawn;
+    if (chunk > count - drawn) chunk = count - drawn;
     if (chunk > 64) chunk = 64;
     uint64_t prod = 0;
     bool rej = false;
@@ -257,12 +262,12 @@ ewc_cost_kernel(const float *__restrict__ w, const float *__restrict__ wstar, co
 }
 
 // ---- launch wrappers (called from the host side in pop.hip) ----
-extern "C" hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B,
+extern "C" hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B, int nupd,
                                          const uint8_t *mask, int *idx_out, int draw, double beta1, double beta2,
                                          const float *lr_a, const float *lr_q, const int *iter_a, const int *iter_q,
-                                         float *lrt_a, float *lrt_q, hipStream_t st) {
-  hipLaunchKernelGGL(replay_draw_kernel, dim3(G), dim3(64), 0, st, mt, pos, rep_len, B, 250, mask, idx_out, draw,
-                     beta1, beta2, lr_a, lr_q, iter_a, iter_q, lrt_a, lrt_q);
+                                         float *lrt_a, float *lrt_q, int *upd_done, hipStream_t st) {
+  hipLaunchKernelGGL(replay_draw_kernel, dim3(G), dim3(64), 0, st, mt, pos, rep_len, B, nupd, 250, mask, idx_out, draw,
+                     beta1, beta2, lr_a, lr_q, iter_a, iter_q, lrt_a, lrt_q, upd_done);
   return hipGetLastError();
 }
 extern "C" hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, hipStream_t st) {

@@ -422,7 +422,7 @@ __device__ __forceinline__ float bias_grad(const float *__restrict__ dYs, int ld
   return (s0 + s1) + (s2 + s3);
 }
 
-template <bool EWC, bool TGT>
+template <bool EWC, bool TGT, bool SETS3 = false>
 __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ldy, int N,
                                            const float *__restrict__ Xs, int ldx, int kp,
                                            int offw, int offb, const OptCtx o,
@@ -445,21 +445,53 @@ __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ld
   OptRegs1 rb;
   const int nb = tid < N ? tid : N - 1;
   opt_load1<EWC, TGT>(o, offb + nb, rb);
-  OptRegs r0, r1;
-  bool ok0 = false, ok1 = false;
-  int i0 = dw_elem(p0, total, KT, N, kp, offw, c, g, ok0), i1 = 0;
-  opt_load4<EWC, TGT>(o, i0, r0);
+  if (SETS3) {
+    // Three sets in rotation: the state of tile s + 2 is requested before tile s is computed (a tile
+    // of products + Adam is ~1.2k cycles, an HBM round trip 4-6k).  Used where the registers allow
+    // it: the callers park the layer's input-gradient accumulators in LDS for the duration.
+    OptRegs r0, r1, r2;
+    bool ok0 = false, ok1 = false, ok2 = false;
+    int i0 = dw_elem(p0, total, KT, N, kp, offw, c, g, ok0), i1 = 0, i2 = 0;
+    opt_load4<EWC, TGT>(o, i0, r0);
+    if (1 < per) { i1 = dw_elem(p0 + 1, total, KT, N, kp, offw, c, g, ok1); opt_load4<EWC, TGT>(o, i1, r1); }
 #pragma unroll 1
-  for (int s = 0; s < per; s += 2) {
-    if (s + 1 < per) { i1 = dw_elem(p0 + s + 1, total, KT, N, kp, offw, c, g, ok1); opt_load4<EWC, TGT>(o, i1, r1); }
-    {
-      const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
-      opt_step4<EWC, TGT>(o, i0, acc, r0, ok0);
+    for (int s = 0; s < per; s += 3) {
+      if (s + 2 < per) { i2 = dw_elem(p0 + s + 2, total, KT, N, kp, offw, c, g, ok2); opt_load4<EWC, TGT>(o, i2, r2); }
+      {
+        const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
+        opt_step4<EWC, TGT>(o, i0, acc, r0, ok0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < per) {
+        if (s + 3 < per) { i0 = dw_elem(p0 + s + 3, total, KT, N, kp, offw, c, g, ok0); opt_load4<EWC, TGT>(o, i0, r0); }
+        const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s + 1, total, KT, c, g);
+        opt_step4<EWC, TGT>(o, i1, acc, r1, ok1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < per) {
+        if (s + 4 < per) { i1 = dw_elem(p0 + s + 4, total, KT, N, kp, offw, c, g, ok1); opt_load4<EWC, TGT>(o, i1, r1); }
+        const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s + 2, total, KT, c, g);
+        opt_step4<EWC, TGT>(o, i2, acc, r2, ok2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (s + 1 < per) {
-      if (s + 2 < per) { i0 = dw_elem(p0 + s + 2, total, KT, N, kp, offw, c, g, ok0); opt_load4<EWC, TGT>(o, i0, r0); }
-      const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s + 1, total, KT, c, g);
-      opt_step4<EWC, TGT>(o, i1, acc, r1, ok1);
+  } else {
+    OptRegs r0, r1;
+    bool ok0 = false, ok1 = false;
+    int i0 = dw_elem(p0, total, KT, N, kp, offw, c, g, ok0), i1 = 0;
+    opt_load4<EWC, TGT>(o, i0, r0);
+  #pragma unroll 1
+    for (int s = 0; s < per; s += 2) {
+      if (s + 1 < per) { i1 = dw_elem(p0 + s + 1, total, KT, N, kp, offw, c, g, ok1); opt_load4<EWC, TGT>(o, i1, r1); }
+      {
+        const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
+        opt_step4<EWC, TGT>(o, i0, acc, r0, ok0);
+      }
+      if (s + 1 < per) {
+        if (s + 2 < per) { i0 = dw_elem(p0 + s + 2, total, KT, N, kp, offw, c, g, ok0); opt_load4<EWC, TGT>(o, i0, r0); }
+        const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s + 1, total, KT, c, g);
+        opt_step4<EWC, TGT>(o, i1, acc, r1, ok1);
+      }
     }
   }
   // bias gradient: column sums of dY (waves whose lanes all sit beyond N skip the LDS reads)

@@ -96,11 +96,13 @@ __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__rest
 // reduction over batch chunks.  nc > 0: the input gradient columns [c0, c0 + nc) are handed to
 // dx0_store(row, col - c0, value); the caller synchronises before other waves read what it wrote.
 enum { DW_NONE = 0, DW_OPT = 1, DW_STORE = 2 };
+#define DDRL_PARK_TILES 4     // input-gradient tiles (of up to DDRL_MAXKC) parked in LDS during a deep layer's optimiser loop
 template <int TRAIN, bool EWC, class ND, class DX0>
 __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w, const OptCtx opt, float *gout,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                         int c0, int nc, DX0 dx0_store, int wave, int lane, int tid,
-                                        long long *bst = nullptr) {   // bst: diagnostic s_memtime slots (dX done / dW done per layer)
+                                        long long *bst = nullptr,     // bst: diagnostic s_memtime slots (dX done / dW done per layer)
+                                        float *park = nullptr) {      // park: DDRL_PARK_TILES * 1 KiB of LDS per wave, dead during the dW loops below the top layer
   const int g = lane >> 4, c = lane & 15;
   float *dZ = top;
   int ldz = ldtop;
@@ -119,7 +121,24 @@ __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w
     if (bst && tid == 0 && ll < 2) bst[2 * ll] = clock64();
     if (TRAIN != DW_NONE) {
       __syncthreads();   // every wave's rows of dZ_l are final and every wave has read W_l
-      if (TRAIN == DW_OPT) bwd_dw_opt<EWC, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+      if (TRAIN == DW_OPT) {
+        // Below the top layer the first DDRL_PARK_TILES input-gradient tiles wait in LDS while the
+        // optimiser loop runs, which makes room for its third state set (the first layer has no
+        // input gradient at all).  Wave-private: no barrier, only the wave's own LDS ordering.
+        const bool deep = park != nullptr && l < nd.L() - 1;
+        if (deep && need_dx) {
+#pragma unroll
+          for (int i = 0; i < DDRL_PARK_TILES; ++i)
+            if (kt0 + i < kt1) *(f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4) = acc[i];
+        }
+        if (deep) bwd_dw_opt<EWC, true, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+        else bwd_dw_opt<EWC, true, false>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+        if (deep && need_dx) {
+#pragma unroll
+          for (int i = 0; i < DDRL_PARK_TILES; ++i)
+            if (kt0 + i < kt1) acc[i] = *(const f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4);
+        }
+      }
       else bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid);
       if (bst && tid == 0 && ll < 2) bst[2 * ll + 1] = clock64();
       __syncthreads();   // every wave has read H_{l-1} before its rows are overwritten by dZ_{l-1}

@@ -9,10 +9,10 @@ size_t ddpg_update_lds_bytes(const DdpgParams *P);
 hipError_t ddpg_update_big_launch(const DdpgParams *P, hipStream_t st);
 hipError_t ddpg_update_wide_launch(const DdpgParams *P, hipStream_t st);
 size_t ddpg_wide_block_floats(const DdpgParams *P);
-hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B, const uint8_t *mask,
+hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G, int B, int nupd, const uint8_t *mask,
                               int *idx_out, int draw, double beta1, double beta2, const float *lr_a,
                               const float *lr_q, const int *iter_a, const int *iter_q, float *lrt_a, float *lrt_q,
-                              hipStream_t st);
+                              int *upd_done, hipStream_t st);
 hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, hipStream_t st);
 hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap, int rowlen, int S, int A,
                                 const float *s, const float *a, const float *r, const float *s2,
@@ -106,6 +106,7 @@ static int validate(const ddrl_ddpg_config *c) {
   if (c->hidden_layer_type < 1 || c->hidden_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "hidden_layer_type not in (1,2,3)");
   if (c->actor_output_layer_type < 0 || c->actor_output_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "actor_output_layer_type not in 0..3");
   if (c->momentum < 0 || c->momentum > 3) return ddrl_fail(DDRL_EINVAL, "momentum not in 0..3");
+  if (c->force_more_update < 0 || c->force_more_update >= DDRL_MAXUPD) return ddrl_fail(DDRL_EINVAL, "force_more_update outside 0..%d", DDRL_MAXUPD - 1);
   if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
   if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
   return DDRL_OK;
@@ -159,6 +160,7 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   if ((rc = dalloc(h, &h->d_mt, (size_t)G * 624))) return bail(rc);
   if ((rc = dalloc(h, &h->d_mtpos, G))) return bail(rc);
   if ((rc = dalloc(h, &h->d_idx, (size_t)G * B))) return bail(rc);
+  h->idx_cap = (size_t)G * B;
   if ((rc = dalloc(h, &h->d_tau, G))) return bail(rc);
   if ((rc = dalloc(h, &h->d_omtau, G))) return bail(rc);
   if ((rc = dalloc(h, &h->d_gamma, G))) return bail(rc);
@@ -229,6 +231,9 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   P.rep = h->d_rep; P.rep_len = h->d_len; P.rep_head = h->d_head; P.idx = h->d_idx;
   P.tau = h->d_tau; P.omtau = h->d_omtau; P.gamma = h->d_gamma;
   P.loss_out = h->d_loss; P.qt_out = h->d_qt; P.dact_out = h->d_dact;
+  if ((rc = dalloc(h, &P.upd_done, G))) return bail(rc);
+  if ((rc = dalloc(h, &P.upd_error, 1))) return bail(rc);
+  P.nupd = 1;
   P.maxchunks = (B + DDRL_MB - 1) / DDRL_MB;
   // nets wider than the LDS-resident kernels take go layer by layer (kernels_ddpg_wide.hip)
   h->wide = S + A > DDRL_MAXW;
@@ -325,6 +330,14 @@ extern "C" int ddrl_pop_destroy(ddrl_pop_t *h) {
 extern "C" int ddrl_pop_sync(ddrl_pop_t *h) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->algo == 0 && h->P.upd_error) {        // raised by a multi-update launch whose ordering wait expired
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, h->P.upd_error, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+      HIPCHK(hipMemset(h->P.upd_error, 0, sizeof(int)));
+      return ddrl_fail(DDRL_ESTATE, "a multi-update launch gave up waiting for an agent's previous update: some updates were skipped");
+    }
+  }
   return DDRL_OK;
 }
 
@@ -526,49 +539,84 @@ extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float
   return DDRL_OK;
 }
 
-extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask) {
-  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
-  DDPG_ONLY(h);
+// n consecutive passes of the fupd loop for every (masked) agent.  idx: host indices [G x n x B] or NULL
+// (device draws).  The one-tile kernel runs them in ONE launch; the chunked / layer-by-layer paths
+// launch n times.
+static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *mask) {
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, B = h->cfg.mini_batch_size;
+  const bool fused = !h->wide && h->P.maxchunks == 1 && !h->force_chunked;
   const uint8_t *dmask;
   if ((rc = upload_mask(h, mask, &dmask))) return rc;
   if (idx) {
     for (int g = 0; g < G; ++g) {
       if (mask && !mask[g]) continue;
       if (h->h_len[g] < 250 || h->h_len[g] < B) continue;
-      for (int i = 0; i < B; ++i)
-        if (idx[(size_t)g * B + i] < 0 || idx[(size_t)g * B + i] >= h->h_len[g])
-          return ddrl_fail(DDRL_EINVAL, "idx[%d][%d]=%d outside the replay of %d samples", g, i, idx[(size_t)g * B + i], h->h_len[g]);
+      for (size_t i = 0; i < (size_t)n * B; ++i)
+        if (idx[(size_t)g * n * B + i] < 0 || idx[(size_t)g * n * B + i] >= h->h_len[g])
+          return ddrl_fail(DDRL_EINVAL, "idx[%d][%zu]=%d outside the replay of %d samples", g, i, idx[(size_t)g * n * B + i], h->h_len[g]);
     }
-    HIPCHK(hipMemcpyAsync(h->d_idx, idx, (size_t)G * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
   }
-  HIPCHK(replay_draw_launch(h->d_mt, h->d_mtpos, h->d_len, G, B, dmask, h->d_idx, idx ? 0 : 1, h->beta1, h->beta2,
-                            h->net[0].d_lr, h->net[1].d_lr, h->net[0].st.iter, h->net[1].st.iter,
-                            h->net[0].st.lr_t, h->net[1].st.lr_t, h->stream));
+  const int per_launch = fused ? n : 1;
+  if ((size_t)G * B * per_launch > h->idx_cap) {       // grows once; the old buffer stays on the handle's free list
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = dalloc(h, &h->d_idx, (size_t)G * B * per_launch))) return rc;
+    h->idx_cap = (size_t)G * B * per_launch;
+    h->P.idx = h->d_idx;
+  }
   h->P.mask = dmask;
   h->P.sgate = h->gates_on ? h->d_sgate : nullptr;
   h->P.agate = h->gates_on ? h->d_agate : nullptr;
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling) {
-    if (h->ev_used == h->ev_pool.size()) {
-      HIPCHK(hipEventCreate(&e0));
-      HIPCHK(hipEventCreate(&e1));
-      h->ev_pool.emplace_back(e0, e1);
+  h->P.nupd = per_launch;
+  std::vector<int32_t> one;
+  for (int l = 0; l < n; l += per_launch) {
+    if (idx) {
+      const int32_t *src = idx;
+      if (!fused && n > 1) {                            // launch l takes update l of every agent
+        one.resize((size_t)G * B);
+        for (int g = 0; g < G; ++g) memcpy(&one[(size_t)g * B], idx + ((size_t)g * n + l) * B, B * sizeof(int32_t));
+        src = one.data();
+      }
+      HIPCHK(hipMemcpyAsync(h->d_idx, src, (size_t)G * B * per_launch * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      if (!fused && n > 1) HIPCHK(hipStreamSynchronize(h->stream));
     }
-    e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second;
-    h->ev_used++;
-    HIPCHK(hipEventRecord(e0, h->stream));
+    HIPCHK(replay_draw_launch(h->d_mt, h->d_mtpos, h->d_len, G, B, per_launch, dmask, h->d_idx, idx ? 0 : 1, h->beta1, h->beta2,
+                              h->net[0].d_lr, h->net[1].d_lr, h->net[0].st.iter, h->net[1].st.iter,
+                              h->net[0].st.lr_t, h->net[1].st.lr_t, h->P.upd_done, h->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) {
+      if (h->ev_used == h->ev_pool.size()) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        h->ev_pool.emplace_back(e0, e1);
+      }
+      e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second;
+      h->ev_used++;
+      HIPCHK(hipEventRecord(e0, h->stream));
+    }
+    if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
+    else if (!fused) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
+    else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
+    if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   }
-  if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
-  else if (h->P.maxchunks > 1 || h->force_chunked) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
-  else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
-  if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  DDPG_ONLY(h);
+  return ddpg_update_n(h, 1, idx, mask);
+}
+
+extern "C" int ddrl_pop_ddpg_update_n(ddrl_pop_t *h, int n, const int32_t *idx, const uint8_t *mask) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  DDPG_ONLY(h);
+  if (n < 1 || n > DDRL_MAXUPD) return ddrl_fail(DDRL_EINVAL, "n outside 1..%d", DDRL_MAXUPD);
+  return ddpg_update_n(h, n, idx, mask);
 }
 
 extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *qt, float *dact) {
@@ -577,7 +625,10 @@ extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, floa
   int rc = set_device(h);
   if (rc) return rc;
   const size_t G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;
-  if (idx) HIPCHK(hipMemcpyAsync(idx, h->d_idx, G * B * 4, hipMemcpyDeviceToHost, h->stream));
+  if (idx) {   // the indices of the last update of the last launch
+    const size_t nu = h->P.nupd > 0 ? h->P.nupd : 1;
+    HIPCHK(hipMemcpy2DAsync(idx, B * 4, h->d_idx + (nu - 1) * B, nu * B * 4, B * 4, G, hipMemcpyDeviceToHost, h->stream));
+  }
   if (loss) HIPCHK(hipMemcpyAsync(loss, h->d_loss, G * 4, hipMemcpyDeviceToHost, h->stream));
   if (qt) HIPCHK(hipMemcpyAsync(qt, h->d_qt, G * B * 4, hipMemcpyDeviceToHost, h->stream));
   if (dact) HIPCHK(hipMemcpyAsync(dact, h->d_dact, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));

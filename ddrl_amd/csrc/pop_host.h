@@ -48,6 +48,7 @@ struct ddrl_pop {
   uint32_t *d_mt = nullptr;
   int *d_mtpos = nullptr;
   int *d_idx = nullptr;
+  size_t idx_cap = 0;              // ints d_idx holds (grows for multi-update launches)
   // developmental gates (null until ddrl_pop_set_gates)
   float *d_sgate = nullptr, *d_agate = nullptr;
   bool gates_on = false;
@@ -190,7 +191,7 @@ static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc, bool target = true) {
   if (target && (rc = dalloc(h, &t.st.wt, n))) return rc;
   if ((rc = dalloc(h, &t.st.iter, h->G))) return rc;
   if ((rc = dalloc(h, &t.d_lr, h->G))) return rc;
-  if ((rc = dalloc(h, &t.st.lr_t, h->G))) return rc;
+  if ((rc = dalloc(h, &t.st.lr_t, (size_t)h->G * DDRL_MAXUPD))) return rc;
   if ((rc = dalloc(h, &t.d_decay, h->G))) return rc;
   t.st.lr = t.d_lr;
   t.st.decay = t.d_decay;

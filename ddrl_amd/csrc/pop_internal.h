@@ -9,6 +9,7 @@
 #define DDRL_NWAVES 8        // 512-thread workgroups: two waves per SIMD; 2 workgroups per CU => 4 waves per SIMD
 #endif
 #define DDRL_NTHREADS (DDRL_NWAVES * 64)
+#define DDRL_MAXUPD 64       // consecutive updates one launch may run (ddrl_pop_ddpg_update_n)
 #define DDRL_MAXB 4096       // largest minibatch (chunks of DDRL_MB rows, kernels_ddpg_big.hip)
 #define DDRL_WIDE_MAXW 1024  // widest layer of the layer-by-layer kernels (kernels_ddpg_wide.hip)
 #define DDRL_MAXW 128        // max layer width handled by the fused (LDS-resident) kernels
@@ -102,7 +103,7 @@ struct NetState {
   float *fisher_nbr;        // [G]
   float *ewc_coef;          // [G] ewc * decay_multiplier if penalty live else 0
   const float *lr;          // [G]
-  float *lr_t;              // [G] lr * sqrt(1-beta2^t)/(1-beta1^t) for the coming update (prep kernel)
+  float *lr_t;              // [G x nupd] lr * sqrt(1-beta2^t)/(1-beta1^t) for the coming update(s) (prep kernel)
   const float *decay;       // [G] L2 weight decay (<0 or 0: off), null if never used
 };
 
@@ -133,6 +134,9 @@ struct DdpgParams {
   // nets wider than DDRL_MAXW (kernels_ddpg_wide.hip): activation tiles in HBM, [G x maxchunks x wide_stride]
   float *wide;
   size_t wide_stride;
+  int nupd;                 // consecutive updates per launch (>= 1): idx is [G x nupd x B], lr_t [G x nupd]
+  int *upd_done;            // [G] updates of this launch an agent has completed (zeroed by the prep kernel)
+  int *upd_error;           // [1] raised when a workgroup gave up waiting for its predecessor
 };
 
 // NFAC(lambda)-V kernels (kernels_nfac.hip)

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("ddrl_pop_infer_dev", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_forward_batch", _i, [_vp, _i, _i, _vp, _vp]),
     ("ddrl_pop_ddpg_update", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_ddpg_update_n", _i, [_vp, _i, _vp, _vp]),
     ("ddrl_pop_ddpg_last", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("ddrl_pop_set_gates", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_get_gates", _i, [_vp, _vp, _vp]),

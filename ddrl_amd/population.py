@@ -206,6 +206,12 @@ class DdpgPopulation(Population):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
         _l.check(self.L.ddrl_pop_ddpg_update(self.h, _p(i), _p(m)))
 
+    def update_n(self, n, idx=None, mask=None):
+        """n consecutive updates per agent in one launch (the fupd loop with force_more_update = n - 1)"""
+        i = None if idx is None else np.ascontiguousarray(idx, np.int32).reshape(self.G, n, self.B)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_ddpg_update_n(self.h, int(n), _p(i), _p(m)))
+
     def last(self):
         idx = np.empty((self.G, self.B), np.int32)
         loss = np.empty(self.G, np.float32)

@@ -133,6 +133,13 @@ int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float *x, float 
  * DeepQNAg.hpp:277).  idx != NULL: host array [G x B] of logical replay indices (0 = oldest).
  * The guard of DeepQNAg.hpp:338 (len >= 250 && len >= B) is applied per agent on the device. */
 int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask);
+/* n consecutive passes of that loop body (the reference runs 1 + force_more_update of them per stored
+ * transition, DeepQNAg.hpp:341; its ddpg.ini has force_more_update=7), each with a freshly sampled
+ * minibatch, in ONE launch for one-tile minibatches: an agent's updates depend only on each other,
+ * so the population is not forced through a grid-wide barrier between them.  Same replay-index
+ * stream and same results as n calls of ddrl_pop_ddpg_update.  idx: NULL or [G x n x B].
+ * 1 <= n <= 64. */
+int ddrl_pop_ddpg_update_n(ddrl_pop_t *h, int n, const int32_t *idx, const uint8_t *mask);
 /* diagnostics of the last update: indices used [G x B], critic loss [G], TD targets [G x B],
  * action gradients fed to the actor [G x B x A].  Any pointer may be NULL. */
 int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *q_targets, float *dact);

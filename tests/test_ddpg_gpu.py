@@ -340,3 +340,43 @@ def test_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, kw):
     a = pop.infer(s)
     for g, ag in enumerate(agents):
         assert np.max(np.abs(a[g] - ag.ann.forward(s[g].astype(np.float64))[0])) <= 1e-5
+
+
+@pytest.mark.parametrize("B,hidden,kw", [(64, (100, 100), dict()), (32, (20,), dict(nstep_return=2, goal_prob=0.1)), (96, (24, 16), dict())])
+def test_fused_consecutive_updates(ora, B, hidden, kw):
+    """ddrl_pop_ddpg_update_n: n passes of the fupd loop in one launch (one-tile minibatches) == n calls of
+    ddrl_pop_ddpg_update, bit for bit, including the replay-index stream; and against the oracle."""
+    G, n = 3, 4
+    popa, agents = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
+    popb, _ = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
+    mask = np.array([1, 0, 1], np.uint8)
+    popa.update_n(n, mask=mask)
+    used = []
+    for _ in range(n):
+        popb.update(mask=mask)
+        used.append(popb.last()["idx"].copy())
+    for net in range(4):
+        assert np.array_equal(popa.weights(net), popb.weights(net)), net
+    for net in (0, 1):
+        for x, y in zip(popa.adam(net), popb.adam(net)):
+            assert np.array_equal(x, y)
+    la, lb = popa.last(), popb.last()
+    for g in range(G):
+        if mask[g]:
+            assert np.array_equal(la["idx"][g], lb["idx"][g]) and la["loss"][g] == lb["loss"][g]
+    assert list(popa.adam(0)[2]) == [n, 0, n]
+    # host indices: [G x n x B]
+    idx = np.stack(used, axis=1)
+    popc, _ = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
+    popc.update_n(n, idx=idx, mask=mask)
+    for net in range(4):
+        assert np.array_equal(popc.weights(net), popb.weights(net)), net
+    # and the oracle, free-running over the same n updates (1e-4 on 99 %: see test_free_running_ten_updates)
+    for g, ag in enumerate(agents):
+        if mask[g]:
+            for u in range(n):
+                ag.update(used[u][g])
+    for net in range(4):
+        w, wo = popa.weights(net), oracle_weights(agents, net)
+        for g in range(G):
+            assert close_frac(w[g], wo[g], 1e-4, 0.99, 1e-2), (net, g)

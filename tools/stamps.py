@@ -31,9 +31,11 @@ print("G=%d ewc=%s  per-WG total cycles median %d (%.1f us @2.1GHz?)" % (G, ewc 
 for i, n in enumerate(names):
     print("%-26s median %8d cycles  %5.1f %%" % (n, np.median(d[:, i]), 100 * np.median(d[:, i]) / np.median(tot)))
 pop.set_profiling(True); pop.profile_read()
-for _ in range(20): pop.update()
+NU = int(os.environ.get("DDRL_NUPD", "1"))
+for _ in range(20):
+    pop.update_n(NU) if NU > 1 else pop.update()
 ms, n = pop.profile_read()
-print("kernel avg %.1f us over %d launches -> %.0f updates/s" % (ms / n * 1e3, n, G * n / ms * 1e3))
+print("kernel avg %.1f us per update (%d updates per launch, %d launches) -> %.0f updates/s" % (ms / n / NU * 1e3, NU, n, G * n * NU / ms * 1e3))
 bw = out[:, 11:15]
 print("critic bwd: dX3 %d | dW3+opt %d | dZ2 write+dX2 %d | dW2+opt %d | dZ1 write + dW1+opt %d" % tuple(np.median(x) for x in (bw[:, 0] - out[:, 4], bw[:, 1] - bw[:, 0], bw[:, 2] - bw[:, 1], bw[:, 3] - bw[:, 2], out[:, 5] - bw[:, 3])))
 for nm, sl in (("round 1 (agents < G/2)", slice(0, G // 2)), ("round 2", slice(G // 2, G))):
