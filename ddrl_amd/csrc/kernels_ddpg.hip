@@ -1,8 +1,9 @@
 // kernels_ddpg.hip -- the fused DDPG population update for gfx950.
 //
-// One launch = one pass of the `fupd` loop body of DeepQNAg::end_episode
+// One launch = one pass (or, P.nupd > 1, several consecutive passes: ddpg_update_kernel below) of the
+// `fupd` loop body of DeepQNAg::end_episode
 // (/root/reference/agent/deepqn/include/DeepQNAg.hpp:343-466) for every agent of the population:
-// one 256-thread workgroup per agent runs all 5 forward passes, both critic backward passes, the
+// one 256-thread workgroup per (pass, agent) runs all 5 forward passes, both critic backward passes, the
 // actor backward pass, both Adam steps (+EWC terms) and both soft target updates without leaving
 // the CU.  The minibatch and all activations live in LDS; weights / optimiser state are touched in
 // HBM exactly once per update by the fused epilogue (opt_step4), plus L2-served re-reads of the
@@ -11,6 +12,8 @@
 // The kernel is a template over the two net shapes.  Instantiated on SNet<...> (compile-time
 // shapes: the BASELINE "mid" and "small" HalfCheetah nets) every loop bound and guard is a
 // constant; instantiated on NetDesc it is the generic kernel for any shape up to DDRL_MAXW.
+// Minibatches above 64 rows: kernels_ddpg_big.hip; layers wider than DDRL_MAXW: kernels_ddpg_wide.hip.
+// DDRL_EXP_* switches are measurement builds, never defined in the product.
 #include "ddpg_device.h"
 
 // one pass of the fupd loop (DeepQNAg.hpp:343-466) for one agent
@@ -25,27 +28,26 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
   const int ldq = nq.ld(nq.L()), lda = na.ld(na.L());
   const int tid = tid0, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: branches on it are uniform, waits are counted exactly
-  const int agent_u = agent;
   const LdsMap M = ddpg_carve(lds, na.L(), nq.L(), P.ldh, ldxc, ldxa, ldq, lda);
 #ifdef DDRL_EXP_STAGGER   // experiment: spread the first round's start times over DDRL_EXP_STAGGER cycles
-  if (agent_u < 512 && u == 0) {
+  if (agent < 512 && u == 0) {
     const long long t0 = clock64();
-    const long long delay = (long long)(((unsigned)agent_u * 2654435761u) >> 8) % DDRL_EXP_STAGGER;
+    const long long delay = (long long)(((unsigned)agent * 2654435761u) >> 8) % DDRL_EXP_STAGGER;
     while (clock64() - t0 < delay) __builtin_amdgcn_s_sleep(32);
   }
 #endif
 
-  long long *stamps = P.stamps ? P.stamps + (size_t)agent_u * 16 : nullptr;
+  long long *stamps = P.stamps ? P.stamps + (size_t)agent * 16 : nullptr;
 #define STAMP(i) do { if (stamps && tid == 0) stamps[i] = clock64(); } while (0)
-  const float *agate = P.agate ? P.agate + (size_t)agent_u * A : nullptr;
-  const float *w_a = P.sa.w + (size_t)agent_u * na.stride(), *w_at = P.sa.wt + (size_t)agent_u * na.stride();
-  const float *w_q = P.sq.w + (size_t)agent_u * nq.stride(), *w_qt = P.sq.wt + (size_t)agent_u * nq.stride();
+  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
+  const float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
 #ifdef DDRL_EXP_HOTW      // experiment: every agent's passes read agent 0's weights (always cache-hot)
   w_a = P.sa.w; w_at = P.sa.wt; w_q = P.sq.w; w_qt = P.sq.wt;
 #endif
 
   STAMP(0);
-  const int *idx = P.idx + ((size_t)agent_u * P.nupd + u) * B;
+  const int *idx = P.idx + ((size_t)agent * P.nupd + u) * B;
   // ---- n-step horizon (DeepQNAg.hpp:360-373, 394-402): the horizon stops before a transition that
   // reached the goal and at the end of the replay; rewards of steps [0, valid) are discounted ----
   // the first weight fragments of the actor-target pass travel while the minibatch is gathered
