@@ -16,6 +16,9 @@
 // DDRL_EXP_* switches are measurement builds, never defined in the product.
 #include "ddpg_device.h"
 
+template <class NA, class NQ> struct ParkOf { static constexpr bool value = NA::kPark && NQ::kPark; };
+template <> struct ParkOf<NetDesc, NetDesc> { static constexpr bool value = false; };
+
 // one pass of the fupd loop (DeepQNAg.hpp:343-466) for one agent
 template <class NA, class NQ, bool EWC_A, bool EWC_Q>
 __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds, int agent, int u, int len, int head,
@@ -103,7 +106,7 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
   // compile-time shapes: the tiles from topq to the end of the allocation (topq after the top layer,
   // topa, the per-row scalars and the tail the host adds, ddpg_update_lds_bytes) are dead during the
   // optimiser loops below the top layer and park input-gradient accumulators there
-  float *park = __is_same(NQ, NetDesc) ? nullptr : M.topq;
+  float *park = ParkOf<NA, NQ>::value ? M.topq : nullptr;
   {
     const OptCtx oq = make_opt<EWC_Q>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B, u);
     bwd_net<DW_OPT, EWC_Q>(nq, w_q, oq, nullptr, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid,
@@ -223,6 +226,8 @@ ddpg_update_kernel(const DdpgParams P) {
   }
 }
 
+static bool ddpg_parks(const DdpgParams *P);
+
 // host-visible LDS sizing, same carve order as the kernel
 extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P) {
   size_t f = 0;
@@ -231,7 +236,7 @@ extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P) {
   // from topq on: the output tiles and per-row scalars, at least the park area of bwd_net
   // (DDRL_PARK_TILES KiB per wave; used by the compile-time instantiations)
   const size_t tail = (size_t)DDRL_MB * (P->q.ld_[P->q.L_] + P->a.ld_[P->a.L_] + 5);
-  const size_t parkf = (size_t)DDRL_NWAVES * DDRL_PARK_TILES * 256;
+  const size_t parkf = ddpg_parks(P) ? (size_t)DDRL_NWAVES * DDRL_PARK_TILES * 256 : 0;
   f += tail > parkf ? tail : parkf;
   return f * sizeof(float);
 }
@@ -242,6 +247,11 @@ typedef SNet<1, 2, 18, 100, 100, 6> MidActor;
 typedef SNet<1, 0, 24, 100, 100, 1> MidCritic;
 typedef SNet<1, 2, 18, 20, 6> SmallActor;
 typedef SNet<1, 0, 24, 50, 7, 1> SmallCritic;
+
+// does the instantiation the launcher will pick park input-gradient tiles (ParkOf)?
+static bool ddpg_parks(const DdpgParams *P) {
+  return MidActor::matches(P->a) && MidCritic::matches(P->q) && ParkOf<MidActor, MidCritic>::value;
+}
 
 template <class NA, class NQ, bool EA, bool EQ>
 static hipError_t launch_t(const DdpgParams *P, size_t lds, hipStream_t st) {

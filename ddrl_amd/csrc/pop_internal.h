@@ -84,6 +84,9 @@ struct SNet {
   __host__ __device__ static constexpr int stride() { return ddrl_roundup(offw(NL), 64); }
   __host__ __device__ static constexpr int hidden_act() { return HACT; }
   __host__ __device__ static constexpr int out_act() { return OACT; }
+  // deep layers with enough tiles per wave to be worth the optimiser's third state set (bwd_net parks
+  // input-gradient tiles in LDS for it, which costs LDS: small nets rather keep a third workgroup per CU)
+  static constexpr bool kPark = NL >= 2 && d(1) >= 64;
   // does a run-time descriptor describe this shape?
   static bool matches(const NetDesc &n) {
     if (n.L_ != NL || n.hidden_act_ != HACT || n.out_act_ != OACT) return false;
