@@ -98,7 +98,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--agents", type=int, default=1024, help="agents per GPU")
     ap.add_argument("--size", default="mid", choices=sorted(SIZES))
     ap.add_argument("--no-ewc", action="store_true")
@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--updates-per-launch", type=int, default=8,
+                    help="consecutive updates per agent fused into one launch (ddrl_pop_ddpg_update_n): the reference's "
+                         "fupd loop, 1 + force_more_update = 8 in its ddpg.ini; bit-identical to separate launches")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,13 +145,23 @@ def main():
     pop.seed_replay((3000 + rank * G + np.arange(G)).astype(np.uint32))
     for g in range(G):
         pop.replay_load(g, synth_rows(rank * G + g, args.replay, S, A))
+    upl = max(1, min(args.updates_per_launch, 64))
+    if max(ha + hq) > 128:
+        upl = 1                      # the layer-by-layer path launches per update anyway
+
+    def run_updates(k):              # k updates of every agent ("steps"), upl per launch
+        full, rem = divmod(k, upl)
+        for _ in range(full):
+            pop.update_n(upl) if upl > 1 else pop.update()
+        if rem:
+            pop.update_n(rem) if rem > 1 else pop.update()
+
     # bring EWC to its steady state: Fisher accumulated, snapshot taken, penalty live
-    pop.update()
+    run_updates(upl)
     if ewc:
         pop.update_best_param(np.ones(G))
         pop.ewc_setup()
-    for _ in range(args.warmup):
-        pop.update()
+    run_updates(args.warmup)
     pop.sync()
 
     def barrier():
@@ -161,8 +174,7 @@ def main():
     pop.profile_read()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pop.update()
+    run_updates(args.steps)
     pop.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -177,13 +189,14 @@ def main():
         return
     byts, flops, Na, Nc = algorithmic_work(S, A, B, ha, hq, ewc)
     value = world * G * args.steps / dt
-    kavg = kernel_ms * 1e-3 / max(launches, 1)
-    achieved = byts * G / kavg
+    kavg = kernel_ms * 1e-3 / max(launches, 1)          # per launch, as rocprofv3 reports it
+    upl_eff = args.steps / max(launches, 1)             # updates per launch actually run
+    achieved = byts * G * upl_eff / kavg
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("bytes_per_launch_%d_%s" % (G, args.size))
+            traffic = json.load(open(tp)).get("bytes_per_launch_%d_%s_upl%d" % (G, args.size, int(round(upl_eff))))
         except Exception:
             traffic = None
     out = {
@@ -192,15 +205,17 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "config 5: DDPG%s + inverting gradients, HalfCheetah dims S=18 A=6, %s nets a=%s q=%s, B=64, "
-                               "%d agents per GPU, replay %d/agent, device mt19937 replay sampling"
-                               % ("+EWC" if ewc else "", args.size, "x".join(map(str, ha)), "x".join(map(str, hq)), G, args.replay),
+                               "%d agents per GPU, replay %d/agent, device mt19937 replay sampling; %d consecutive updates per launch "
+                               "(the fupd loop, force_more_update=%d)"
+                               % ("+EWC" if ewc else "", args.size, "x".join(map(str, ha)), "x".join(map(str, hq)), G, args.replay, upl, upl - 1),
                    "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "kernel": "ddpg_update_kernel" if max(ha + hq) <= 128 else "wide_* layer kernels + ddpg_apply_kernel (one update = 45 launches)",
                      "kernel_avg_ms": kavg * 1e3, "launches": launches,
+                     "updates_per_launch": upl_eff, "algorithmic_bytes_per_launch": byts * G * upl_eff,
                      "algorithmic_bytes_per_agent_update": byts,
-                     "mfma_f32_frac": flops * G / kavg / MFMA_F32_PEAK, "flops_per_agent_update": flops},
+                     "mfma_f32_frac": flops * G * upl_eff / kavg / MFMA_F32_PEAK, "flops_per_agent_update": flops},
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -74,6 +74,7 @@ __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &
   o.fisher_beta = P.fisher_beta;
   o.nsample = nsample;
   o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
+  o.handoff = P.nupd > 1;
   return o;
 }
 

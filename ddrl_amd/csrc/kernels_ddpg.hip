@@ -164,10 +164,17 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
   }
   STAMP(10);
   if (tid == 0) {
-    P.sq.iter[agent] += 1;                                               // Solver::Step ++iter
-    P.sa.iter[agent] += 1;                                               // set_iter(iter()+1) :459
-    if (EWC_Q) P.sq.fisher_nbr[agent] = P.sq.fisher_nbr[agent] * P.fisher_beta + (float)B;
-    if (EWC_A) P.sa.fisher_nbr[agent] = P.sa.fisher_nbr[agent] * P.fisher_beta + (float)B;
+    if (P.nupd > 1) {     // read by the agent's next update in this launch: sc1 stores (see store_sc1)
+      __hip_atomic_store(P.sq.iter + agent, P.sq.iter[agent] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.sa.iter + agent, P.sa.iter[agent] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (EWC_Q) store_sc1(P.sq.fisher_nbr + agent, P.sq.fisher_nbr[agent] * P.fisher_beta + (float)B);
+      if (EWC_A) store_sc1(P.sa.fisher_nbr + agent, P.sa.fisher_nbr[agent] * P.fisher_beta + (float)B);
+    } else {
+      P.sq.iter[agent] += 1;                                             // Solver::Step ++iter
+      P.sa.iter[agent] += 1;                                             // set_iter(iter()+1) :459
+      if (EWC_Q) P.sq.fisher_nbr[agent] = P.sq.fisher_nbr[agent] * P.fisher_beta + (float)B;
+      if (EWC_A) P.sa.fisher_nbr[agent] = P.sa.fisher_nbr[agent] * P.fisher_beta + (float)B;
+    }
   }
 }
 
@@ -214,15 +221,11 @@ ddpg_update_kernel(const DdpgParams P) {
   }
   ddpg_update_once<NA, NQ, EWC_A, EWC_Q>(P, lds, agent, u, len, head, gamma, tau, omtau);
   if (P.nupd > 1) {
-    // producer side: every storing wave waits for its stores, the barrier, then ONE lane's agent-scope
-    // release (writes the XCD L2's dirty lines back), its wait, and only then the counter
+    // producer side: everything the agent's next update reads was stored sc1 (store_sc1: no L2 write-back
+    // needed); every storing wave waits for its stores, the barrier, and only then the counter (an sc1 store)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(P.upd_done + agent, u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(P.upd_done + agent, u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -221,6 +221,7 @@ nfac_apply_kernel(const NfacParams P, int iter_add, int last) {
   o.ewc_coef = EWC ? st.ewc_coef[agent] : 0.f;
   o.fisher_beta = P.fisher_beta; o.nsample = nsample;
   o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
+  o.handoff = 0;
   const int i = (blockIdx.x * 256 + tid) * 4;
   if (i < nd.stride()) {
     OptRegs r;

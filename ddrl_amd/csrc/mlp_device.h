@@ -246,6 +246,7 @@ struct OptCtx {
   const float *fhat, *wstar;
   float lr_t, tau, omtau, decay, ewc_coef, fisher_beta, nsample;
   float beta1, beta2, omb1, omb2, eps;
+  int handoff;       // the state is read by ANOTHER workgroup later in this launch (multi-update launches): sc1 stores
 };
 
 // 1 / (sqrt(v) + eps) on the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 instead of the ~25-instruction
@@ -270,6 +271,17 @@ template <bool NT> __device__ __forceinline__ void stream_st(float *p, f32x4 x) 
   if (NT) { __builtin_nontemporal_store(x, (f32x4 *)p); return; }
 #endif
   *(f32x4 *)p = x;
+}
+
+// Stores that another workgroup of the same launch will read (MI355X_MICROARCH.md, inter-workgroup
+// visibility): `sc1` stores leave the XCD's L2 by themselves, so the hand-off needs no L2 write-back
+// (`buffer_wbl2`) at its release -- only every storing wave's vmcnt(0), the barrier and the flag.  16-byte
+// sc1 stores run at the plain rate; the 4-byte ones (biases, counters) are few.
+__device__ __forceinline__ void store_sc1(float *p, f32x4 x) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void store_sc1(float *p, float x) {
+  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Optimiser state of 4 consecutive parameters, requested before the products that produce their
@@ -316,11 +328,19 @@ __device__ __forceinline__ void opt_step4(const OptCtx o, int i, f32x4 grad, con
   ok = ok && (w[0] + wt[1] + m[2] + v[3] + (EWC ? f[0] : 0.f) == 12345.678f);
 #endif
   if (ok) {                                   // stores only: nothing waits on them
-    if (EWC) stream_st<NT>(o.fisher + i, f);
-    stream_st<NT>(o.m + i, m);
-    stream_st<NT>(o.v + i, v);
-    *(f32x4 *)(o.w + i) = w;
-    if (TGT) *(f32x4 *)(o.wt + i) = wt;
+    if (o.handoff) {                          // uniform
+      if (EWC) store_sc1(o.fisher + i, f);
+      store_sc1(o.m + i, m);
+      store_sc1(o.v + i, v);
+      store_sc1(o.w + i, w);
+      if (TGT) store_sc1(o.wt + i, wt);
+    } else {
+      if (EWC) stream_st<NT>(o.fisher + i, f);
+      stream_st<NT>(o.m + i, m);
+      stream_st<NT>(o.v + i, v);
+      *(f32x4 *)(o.w + i) = w;
+      if (TGT) *(f32x4 *)(o.wt + i) = wt;
+    }
   }
 }
 
@@ -362,11 +382,19 @@ __device__ __forceinline__ void opt_step1(const OptCtx o, int i, float grad, con
   const float v = o.omb2 * (grad * grad) + o.beta2 * r.v;
   w -= o.lr_t * (m * adam_rdenom(v, o.eps));
   if (ok) {
-    if (EWC) o.fisher[i] = f;
-    o.m[i] = m;
-    o.v[i] = v;
-    o.w[i] = w;
-    if (TGT) o.wt[i] = o.tau * w + o.omtau * r.wt;
+    if (o.handoff) {
+      if (EWC) store_sc1(o.fisher + i, f);
+      store_sc1(o.m + i, m);
+      store_sc1(o.v + i, v);
+      store_sc1(o.w + i, w);
+      if (TGT) store_sc1(o.wt + i, o.tau * w + o.omtau * r.wt);
+    } else {
+      if (EWC) o.fisher[i] = f;
+      o.m[i] = m;
+      o.v[i] = v;
+      o.w[i] = w;
+      if (TGT) o.wt[i] = o.tau * w + o.omtau * r.wt;
+    }
   }
 }
 

@@ -18,9 +18,11 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         for row in csv.DictReader(fh):
             key = (f, row["Dispatch_Id"], row["Counter_Name"])
             per_dispatch[key] += float(row["Counter_Value"])
-            names[(f, row["Dispatch_Id"])] = row["Kernel_Name"]
+            # launches of one kernel with different grids are different workloads (the update kernel runs
+            # G x updates-per-launch workgroups): the grid size is part of the key
+            names[(f, row["Dispatch_Id"])] = "%s [grid %s]" % (row["Kernel_Name"].split("(")[0][:60], row.get("Grid_Size", "?"))
     for (ff, d, c), v in per_dispatch.items():
-        acc[names[(ff, d)].split("(")[0][:60]][c].append(v)
+        acc[names[(ff, d)]][c].append(v)
 out = {}
 for k, cs in sorted(acc.items()):
     out[k] = {c: sum(v) / len(v) for c, v in cs.items()}
