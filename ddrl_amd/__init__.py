@@ -5,6 +5,6 @@ include/ddrl_pop.h).  This package is the thin Python mirror of that ABI used by
 it has no CPU path and raises if the library is missing.
 """
 from .lib import load, LibraryMissing, DdrlError  # noqa: F401
-from .population import DdpgConfig, DdpgPopulation, NfacConfig, NfacPopulation, PolicyPopulation  # noqa: F401
+from .population import DdpgConfig, DdpgPopulation, Td3Population, NfacConfig, NfacPopulation, PolicyPopulation  # noqa: F401
 from .cmaes import Cmaes  # noqa: F401
-from .agents import DdpgAgents, NfacAgents, CmaesAgents, DDRLAg  # noqa: F401
+from .agents import DdpgAgents, Td3Agents, NfacAgents, CmaesAgents, DDRLAg  # noqa: F401

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _l
-from .population import NfacPopulation, PolicyPopulation, Population, _p
+from .population import NfacPopulation, PolicyPopulation, Population, Td3Population, _p
 
 
 class _Borrowed(Population):
@@ -72,6 +72,22 @@ class DdpgAgents(_Agents):
         self._adopt(h, n_agents, nb_sensors, nb_motors)
 
 
+class _BorrowedTd3(_Borrowed, Td3Population):
+    pass
+
+
+class Td3Agents(_Agents):
+    """G TD3 agents (TD3Ag.hpp): DeepQNAg's front end, one update per stored transition, the actor and
+    the targets every policy_freq-th step of an episode."""
+    _view = _BorrowedTd3
+
+    def __init__(self, ini_path, n_agents, nb_sensors, nb_motors, seed=0, device=-1):
+        self.L = _l.load()
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_agents_create_td3(ini_path.encode(), n_agents, nb_sensors, nb_motors, device, seed, C.byref(h)))
+        self._adopt(h, n_agents, nb_sensors, nb_motors)
+
+
 class _BorrowedNfac(_Borrowed, NfacPopulation):
     pass
 
@@ -125,13 +141,14 @@ class CmaesAgents(_Agents):
 
 class DDRLAg:
     """gym/agent.py's DDRLAg against libddrl_pop.so: same methods, same DDPGAg_* (algo="ddpg") or
-    OfflineCaclaAg_* (algo="nfac") calls."""
+    OfflineCaclaAg_* (algo="nfac") calls; algo="td3" = the DDPGAg_* calls of the reference's libddrl-td3,
+    here under the TD3Ag_ prefix."""
 
     def __init__(self, nb_motors, nb_sensors, argv=(), algo="ddpg"):
         self.L = _l.load()
         self.nb_motors, self.nb_sensors = nb_motors, nb_sensors
-        self._pre = {"ddpg": "DDPGAg_", "nfac": "OfflineCaclaAg_"}[algo]
-        self._name = {"ddpg": "DDPG", "nfac": "NFAC(lambda)-V"}[algo]
+        self._pre = {"ddpg": "DDPGAg_", "nfac": "OfflineCaclaAg_", "td3": "TD3Ag_"}[algo]
+        self._name = {"ddpg": "DDPG", "nfac": "NFAC(lambda)-V", "td3": "TD3"}[algo]
         self.obj = self._f("new")(nb_motors, nb_sensors)
         argv = list(argv) + [""]
         arr = (C.c_char_p * len(argv))(*[a.encode("utf-8") for a in argv])

@@ -18,6 +18,7 @@ struct AgentState {
   double last_receive_reward = 0.;
   bool last_episode_learning = false, have_last = false;
   int episode = 0, step = 0;
+  int td3_step = 0;                          // TD3Ag::current_step_counter (TD3Ag.hpp:157, 244)
   std::vector<double> ou_x;                  // OrnsteinUhlenbeckNoise::x_t
   std::mt19937 engine;
 };
@@ -46,7 +47,8 @@ struct ddrl_agents {
   int G = 0, S = 0, A = 0;
   double gamma = 0.99, noise = 0., noise2 = 0., noise3 = 0., reward_scale = 1.;
   int gaussian_policy = 0, decision_each = 1, force_more_update = 0;
-  int algo = 0;                              // 0 DDPG (DeepQNAg), 1 NFAC (OfflineCaclaAg), 2 CMA-ES (CMAESAg)
+  int algo = 0;                              // 0 DDPG (DeepQNAg), 1 NFAC (OfflineCaclaAg), 2 CMA-ES (CMAESAg), 3 TD3 (TD3Ag)
+  int policy_freq = 1;                       // TD3Ag.hpp:186
   int update_each_episode = 1;
   // CMAESAg: one agent slot per individual of the generation
   ddrl_cmaes_t *es = nullptr;
@@ -341,6 +343,33 @@ extern "C" int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int n
   return DDRL_OK;
 }
 
+// TD3Ag (agent/deepqn/include/TD3Ag.hpp:95-98, 165-231): DeepQNAg's front end with one update per
+// stored transition, the actor and the targets moving every policy_freq-th step of the episode
+extern "C" int ddrl_agents_create_td3(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int device,
+                                      uint64_t seed, ddrl_agents_t **out) {
+  if (!ini_path || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  *out = nullptr;
+  ddrl_ddpg_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.n_agents = n_agents; cfg.nb_sensors = nb_sensors; cfg.nb_motors = nb_motors; cfg.device = device;
+  int rc = ddrl_td3_config_from_ini(ini_path, &cfg);
+  if (rc) return rc;
+  std::unique_ptr<ddrl_agents> h(new ddrl_agents());
+  h->algo = 3;
+  DdrlIni ini;
+  if ((rc = read_common(h.get(), ini_path, ini))) return rc;
+  h->gamma = cfg.gamma;
+  h->policy_freq = cfg.policy_freq;
+  if ((rc = ddrl_td3_create(&cfg, seed, &h->pop))) return rc;
+  init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
+  if ((rc = read_devnn(h.get(), ini, ini_path)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
+  std::vector<uint32_t> rs(cfg.n_agents);
+  for (int g = 0; g < cfg.n_agents; ++g) rs[g] = (uint32_t)(seed * 40503ull + 7919u * g + 17u);
+  if ((rc = ddrl_pop_seed_replay(h->pop, rs.data()))) { ddrl_agents_destroy(h.release()); return rc; }
+  *out = h.release();
+  return DDRL_OK;
+}
+
 // OfflineCaclaAg (agent/cacla/include/OfflineCaclaAg.hpp:59-62, 122-209).  max_trajectory <= 0: the
 // buffer is sized from environment.max_step_per_instance / decision_each x update_each_episode when the
 // ini has it, 1024 x update_each_episode otherwise.
@@ -514,6 +543,7 @@ extern "C" int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states, 
     std::fill(s.ou_x.begin(), s.ou_x.end(), 0.);
     s.have_last = false;
     s.step = 0;
+    s.td3_step = 0;                                       // TD3Ag.hpp:244
   }
   if (h->algo == 2) return cmaes_start_instance(h, learning, mask);
   if (h->dev.on) return dev_start_episode(h, learning, mask);
@@ -523,6 +553,13 @@ extern "C" int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states, 
 // one update round = 1 + force_more_update passes of the fupd loop (DeepQNAg.hpp:341); the
 // replay-size guard (:338) is applied per agent on the device
 static int update_round(ddrl_agents *h, const uint8_t *mask) {
+  if (h->algo == 3) {
+    // TD3Ag::end_episode (TD3Ag.hpp:284-380): one update; the actor and the targets move when
+    // current_step_counter % policy_freq == 0 (:333)
+    std::vector<uint8_t> astep(h->G, 0);
+    for (int g = 0; g < h->G; ++g) astep[g] = h->ag[g].td3_step % h->policy_freq == 0;
+    return ddrl_pop_td3_update(h->pop, nullptr, nullptr, astep.data(), mask);
+  }
   return ddrl_pop_ddpg_update_n(h->pop, 1 + h->force_more_update, nullptr, mask);   // one launch for the whole fupd loop
 }
 
@@ -555,8 +592,10 @@ extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const floa
     // next_action = ann_testing->computeOut(sensors) with the weights BEFORE this step's update (:126)
     int rc = ddrl_pop_infer(h->pop, states, h->pure.data());
     if (rc) return rc;
-    if (any_insert && h->algo == 0) {
-      // insertSample: push {last_state, last_action, sensors, reward, goal}, then end_episode(true) (:159-165)
+    if (any_insert && (h->algo == 0 || h->algo == 3)) {
+      // insertSample: push {last_state, last_action, sensors, reward, goal}, then end_episode(true) (:159-165;
+      // TD3Ag.hpp:156-163 counts the step first)
+      for (int g = 0; g < G; ++g) if (h->insert_mask[g]) h->ag[g].td3_step++;
       if ((rc = ddrl_pop_replay_append(h->pop, h->last_state.data(), h->last_action.data(), h->rew.data(), states,
                                        h->goal.data(), h->insert_mask.data()))) return rc;
       if ((rc = update_round(h, h->insert_mask.data()))) return rc;
@@ -639,7 +678,7 @@ extern "C" int ddrl_agents_end_episode(ddrl_agents_t *h, const uint8_t *learning
     return ddrl_pop_sync(h->pop);
   }
   if (any_l && (rc = update_round(h, lm.data()))) return rc;
-  if (h->pop->cfg.ewc >= 0.) {
+  if (h->pop->cfg.ewc >= 0. && h->algo != 3) {            // TD3Ag::end_instance only counts the episode (TD3Ag.hpp:278-282)
     if (any_l && method <= 3 && (rc = ddrl_pop_update_best_param(h->pop, score.data(), lm.data()))) return rc;
     if (any_l && (rc = ddrl_pop_ewc_decay_update(h->pop, lm.data()))) return rc;
     if (any_t && method >= 4 && (rc = ddrl_pop_update_best_param(h->pop, score.data(), tm.data()))) return rc;
@@ -690,8 +729,9 @@ extern "C" void DDPGAg_unique_invoke(int64_t hnd, int argc, char **argv) {
     else if (a == "--seed" && i + 1 < argc && argv[i + 1]) seed = strtoull(argv[++i], nullptr, 10);
   }
   const int rc = s->algo == 0 ? ddrl_agents_create_ddpg(config.c_str(), 1, (int)s->nb_sensors, (int)s->nb_motors, -1, seed, &s->ag)
+               : s->algo == 3 ? ddrl_agents_create_td3(config.c_str(), 1, (int)s->nb_sensors, (int)s->nb_motors, -1, seed, &s->ag)
                               : ddrl_agents_create_nfac(config.c_str(), 1, (int)s->nb_sensors, (int)s->nb_motors, 0, -1, seed, &s->ag);
-  if (rc != DDRL_OK) fprintf(stderr, "%s_unique_invoke: %s\n", s->algo == 0 ? "DDPGAg" : "OfflineCaclaAg", ddrl_last_error());
+  if (rc != DDRL_OK) fprintf(stderr, "%s_unique_invoke: %s\n", s->algo == 0 ? "DDPGAg" : s->algo == 3 ? "TD3Ag" : "OfflineCaclaAg", ddrl_last_error());
 }
 
 extern "C" void DDPGAg_start_episode(int64_t hnd, const double *state, bool learning) {
@@ -746,7 +786,7 @@ static int save_load(DDPGAgShim *s, int episode, bool save) {
   FILE *f = fopen(path.c_str(), save ? "wb" : "rb");
   if (!f) return ddrl_fail(DDRL_EIO, "cannot open %s", path.c_str());
   int rc = DDRL_OK;
-  for (int net = 0; net < (s->algo == 0 ? 4 : 2) && rc == DDRL_OK; ++net) {
+  for (int net = 0; net < (s->algo == 0 ? 4 : s->algo == 3 ? 6 : 2) && rc == DDRL_OK; ++net) {
     const int n = ddrl_pop_num_params(s->ag->pop, net);
     std::vector<double> w(n);
     if (save) {
@@ -797,3 +837,23 @@ extern "C" void OfflineCaclaAg_display(int64_t ag, bool learning, int episode, i
 extern "C" void OfflineCaclaAg_save(int64_t ag, int episode) { DDPGAg_save(ag, episode); }
 extern "C" void OfflineCaclaAg_load(int64_t ag, int episode) { DDPGAg_load(ag, episode); }
 extern "C" void OfflineCaclaAg_delete(int64_t ag) { DDPGAg_delete(ag); }
+
+// TD3: the reference builds the same binding file with WANT_TD3 into libddrl-td3, which therefore exports
+// the DDPGAg_* names (agent/deepqn/src/pybinding/ddpg.cpp:3-5, CMakeLists.txt:84-88; gym/agent.py:112,157).
+// One library cannot export them twice: here the TD3 flavour carries its own prefix, same signatures.
+extern "C" int64_t TD3Ag_new(unsigned nb_motors, unsigned nb_sensors) {
+  DDPGAgShim *s = (DDPGAgShim *)(intptr_t)DDPGAg_new(nb_motors, nb_sensors);
+  s->algo = 3;
+  return (int64_t)(intptr_t)s;
+}
+extern "C" void TD3Ag_unique_invoke(int64_t ag, int argc, char **argv) { DDPGAg_unique_invoke(ag, argc, argv); }
+extern "C" void TD3Ag_start_episode(int64_t ag, const double *state, bool learning) { DDPGAg_start_episode(ag, state, learning); }
+extern "C" const double *TD3Ag_run(int64_t ag, double reward, const double *sensors, bool learning, bool goal_reached, bool last) {
+  return DDPGAg_run(ag, reward, sensors, learning, goal_reached, last);
+}
+extern "C" void TD3Ag_end_episode(int64_t ag, bool learning) { DDPGAg_end_episode(ag, learning); }
+extern "C" void TD3Ag_dump(int64_t ag, bool learning, int episode, int step, double treward) { DDPGAg_dump(ag, learning, episode, step, treward); }
+extern "C" void TD3Ag_display(int64_t ag, bool learning, int episode, int step, double treward) { DDPGAg_display(ag, learning, episode, step, treward); }
+extern "C" void TD3Ag_save(int64_t ag, int episode) { DDPGAg_save(ag, episode); }
+extern "C" void TD3Ag_load(int64_t ag, int episode) { DDPGAg_load(ag, episode); }
+extern "C" void TD3Ag_delete(int64_t ag) { DDPGAg_delete(ag); }

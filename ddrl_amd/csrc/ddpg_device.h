@@ -10,6 +10,17 @@ __device__ __forceinline__ bool gather_owns_row(int tid, int &row) {
   return tid - row * DDRL_GATHER_TPR == 0;
 }
 
+// compile-time shapes: BASELINE.md section 3 "mid" (a=100,100 / q=100,100) and "small" (a=20 / q=50,7,
+// agent/deepqn/data/ddpg-cp.ini:15-16) HalfCheetah nets (S=18, A=6), leaky-ReLU hidden, tanh actor output
+typedef SNet<1, 2, 18, 100, 100, 6> MidActor;
+typedef SNet<1, 0, 24, 100, 100, 1> MidCritic;
+typedef SNet<1, 2, 18, 20, 6> SmallActor;
+typedef SNet<1, 0, 24, 50, 7, 1> SmallCritic;
+
+// does an instantiation park input-gradient tiles in LDS during the deep layers' optimiser loops (bwd_net)?
+template <class NA, class NQ> struct ParkOf { static constexpr bool value = NA::kPark && NQ::kPark; };
+template <> struct ParkOf<NetDesc, NetDesc> { static constexpr bool value = false; };
+
 struct LdsMap {
   float *hbase; int hstride; // hidden activation l (1..L-1) of the pass in flight lives at hbase + (l-1)*hstride
   float *xc, *xa;            // critic input [s|a] tile, actor input s tile

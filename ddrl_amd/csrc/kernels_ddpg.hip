@@ -16,9 +16,6 @@
 // DDRL_EXP_* switches are measurement builds, never defined in the product.
 #include "ddpg_device.h"
 
-template <class NA, class NQ> struct ParkOf { static constexpr bool value = NA::kPark && NQ::kPark; };
-template <> struct ParkOf<NetDesc, NetDesc> { static constexpr bool value = false; };
-
 // one pass of the fupd loop (DeepQNAg.hpp:343-466) for one agent
 template <class NA, class NQ, bool EWC_A, bool EWC_Q>
 __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds, int agent, int u, int len, int head,
@@ -243,13 +240,6 @@ extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P) {
   f += tail > parkf ? tail : parkf;
   return f * sizeof(float);
 }
-
-// compile-time shapes: BASELINE.md section 3 "mid" (a=100,100 / q=100,100) and "small" (a=20 / q=50,7,
-// agent/deepqn/data/ddpg-cp.ini:15-16) HalfCheetah nets (S=18, A=6), leaky-ReLU hidden, tanh actor output
-typedef SNet<1, 2, 18, 100, 100, 6> MidActor;
-typedef SNet<1, 0, 24, 100, 100, 1> MidCritic;
-typedef SNet<1, 2, 18, 20, 6> SmallActor;
-typedef SNet<1, 0, 24, 50, 7, 1> SmallCritic;
 
 // does the instantiation the launcher will pick park input-gradient tiles (ParkOf)?
 static bool ddpg_parks(const DdpgParams *P) {

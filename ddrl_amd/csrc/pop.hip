@@ -13,6 +13,10 @@ hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G,
                               int *idx_out, int draw, double beta1, double beta2, const float *lr_a,
                               const float *lr_q, const int *iter_a, const int *iter_q, float *lrt_a, float *lrt_q,
                               int *upd_done, hipStream_t st);
+hipError_t td3_update_launch(const DdpgParams *P, int force_generic, hipStream_t st);
+hipError_t td3_prep_launch(const uint64_t *seed, uint32_t *count, const int *rep_len, int G, int B, int A,
+                           const uint8_t *mask, float *noise, int draw, float sigma, float clip, double beta1,
+                           double beta2, const float *lr_q2, const int *iter_q2, float *lrt_q2, hipStream_t st);
 hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, hipStream_t st);
 hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap, int rowlen, int S, int A,
                                 const float *s, const float *a, const float *r, const float *s2,
@@ -43,10 +47,15 @@ extern "C" int ddrl_ddpg_config_default(ddrl_ddpg_config *c) {
   c->gamma = 0.99; c->tau_soft_update = 0.001; c->alpha_a = 1e-4; c->alpha_v = 1e-3; c->decay_v = -1.;
   c->ewc = -1.; c->ewc_decay = -1.; c->ewc_fisher_beta = 0.999; c->ewc_best_param_method = 0; c->ewc_for_critic = 0;
   c->device = -1;
+  c->td3 = 0; c->policy_freq = 2; c->policy_noise = 0.2; c->noise_clip = 0.5;   // (TD3 paper defaults; the reference ships no td3 ini)
   return DDRL_OK;
 }
 
-extern "C" int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *c) {
+static int config_from_ini(const char *path, ddrl_ddpg_config *c, bool td3);
+extern "C" int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *c) { return config_from_ini(path, c, false); }
+extern "C" int ddrl_td3_config_from_ini(const char *path, ddrl_ddpg_config *c) { return config_from_ini(path, c, true); }
+
+static int config_from_ini(const char *path, ddrl_ddpg_config *c, bool td3) {
   if (!path || !c) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   DdrlIni ini;
   std::string err;
@@ -66,8 +75,15 @@ extern "C" int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *c) 
     c->gamma = ini.get_double("agent.gamma");
     c->mini_batch_size = (int)ini.get_long("agent.mini_batch_size");
     c->replay_memory = (int)ini.get_long("agent.replay_memory");
-    c->inverting_grad = ini.get_bool("agent.inverting_grad");
-    c->force_more_update = (int)ini.get_long("agent.force_more_update");
+    if (td3) {                                     // TD3Ag.hpp:165-186 reads neither of the three DDPG-only keys
+      c->td3 = 1; c->inverting_grad = 0; c->force_more_update = 0;
+      c->policy_noise = ini.get_double("agent.policy_noise");
+      c->noise_clip = ini.get_double("agent.noise_clip");
+      c->policy_freq = (int)ini.get_long("agent.policy_freq");
+    } else {
+      c->inverting_grad = ini.get_bool("agent.inverting_grad");
+      c->force_more_update = (int)ini.get_long("agent.force_more_update");
+    }
     c->tau_soft_update = ini.get_double("agent.tau_soft_update");
     c->alpha_a = ini.get_double("agent.alpha_a");
     c->alpha_v = ini.get_double("agent.alpha_v");
@@ -77,7 +93,7 @@ extern "C" int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *c) 
     c->actor_output_layer_type = (int)ini.get_long("agent.actor_output_layer_type");
     c->hidden_layer_type = (int)ini.get_long("agent.hidden_layer_type");
     c->momentum = (int)ini.get_long("agent.momentum");
-    c->nstep_return = (int)ini.get_long("agent.nstep_return");
+    if (!td3) c->nstep_return = (int)ini.get_long("agent.nstep_return");
     if (ini.has("devnn.ewc")) c->ewc = ini.get_double("devnn.ewc");
     if (c->ewc >= 0.) {
       if (ini.has("devnn.ewc_decay")) c->ewc_decay = ini.get_double("devnn.ewc_decay");
@@ -109,6 +125,17 @@ static int validate(const ddrl_ddpg_config *c) {
   if (c->force_more_update < 0 || c->force_more_update >= DDRL_MAXUPD) return ddrl_fail(DDRL_EINVAL, "force_more_update outside 0..%d", DDRL_MAXUPD - 1);
   if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
   if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
+  if (c->td3) {
+    if (c->policy_freq < 1) return ddrl_fail(DDRL_EINVAL, "policy_freq < 1");
+    if (!(c->policy_noise >= 0.) || !(c->noise_clip >= 0.)) return ddrl_fail(DDRL_EINVAL, "policy_noise / noise_clip < 0");
+    if (c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "TD3: mini_batch_size > %d is not supported in this round", DDRL_MB);
+    bool wide = c->nb_sensors + c->nb_motors > DDRL_MAXW;
+    for (int i = 0; i < c->n_hidden_a; ++i) wide = wide || c->hidden_unit_a[i] > DDRL_MAXW;
+    for (int i = 0; i < c->n_hidden_q; ++i) wide = wide || c->hidden_unit_q[i] > DDRL_MAXW;
+    if (wide) return ddrl_fail(DDRL_EINVAL, "TD3: layers wider than %d are not supported in this round", DDRL_MAXW);
+    if (c->nstep_return > 0 || c->inverting_grad || c->force_more_update)
+      return ddrl_fail(DDRL_EINVAL, "TD3Ag has no nstep_return / inverting_grad / force_more_update");
+  }
   return DDRL_OK;
 }
 
@@ -153,6 +180,19 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   const bool ewc = cfg->ewc >= 0.;
   if ((rc = alloc_net(h, h->net[0], ewc))) return bail(rc);
   if ((rc = alloc_net(h, h->net[1], ewc && cfg->ewc_for_critic >= 1))) return bail(rc);   // DODevMLP.hpp:714-720
+  if (cfg->td3) {                                          // TD3Ag.hpp:221-229: qnn2 like qnn
+    h->nnets = 3;
+    h->net[2].nd = h->net[1].nd;
+    if ((rc = alloc_net(h, h->net[2], ewc && cfg->ewc_for_critic >= 1))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_nseed, G))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_ncount, G))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_noise, (size_t)G * B * A))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_loss2, G))) return bail(rc);
+    if ((rc = dalloc(h, &h->d_astep, G))) return bail(rc);
+    std::vector<uint64_t> ns(G);
+    for (int g = 0; g < G; ++g) ns[g] = init_seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull * (uint64_t)(g + 1);
+    if ((rc = upload_vec(h, h->d_nseed, ns))) return bail(rc);
+  }
   h->rowlen = ddrl_roundup(2 * S + A + 2, 4);
   if ((rc = dalloc(h, &h->d_rep, (size_t)G * cfg->replay_memory * h->rowlen, false))) return bail(rc);
   if ((rc = dalloc(h, &h->d_len, G))) return bail(rc);
@@ -201,7 +241,7 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   {
     std::mt19937_64 eng(init_seed);
     std::normal_distribution<double> nd01(0.0, 0.01);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < h->nnets; ++k) {
       std::vector<double> flat((size_t)G * h->net[k].nd.np);
       for (auto &x : flat) x = nd01(eng);
       if ((rc = upload_flat(h, h->net[k].nd, h->net[k].st.w, flat.data()))) return bail(rc);
@@ -213,7 +253,8 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   DdpgParams &P = h->P;
   memset(&P, 0, sizeof(P));
   P.a = h->net[0].nd; P.q = h->net[1].nd;
-  P.sa = h->net[0].st; P.sq = h->net[1].st;
+  P.sa = h->net[0].st; P.sq = h->net[1].st; P.sq2 = h->net[2].st;
+  P.noise = h->d_noise; P.loss2_out = h->d_loss2;
   P.G = G; P.S = S; P.A = A; P.B = B; P.cap = cfg->replay_memory; P.rowlen = h->rowlen;
   P.inverting = cfg->inverting_grad ? 1 : 0;
   P.nstep = cfg->nstep_return;
@@ -351,6 +392,7 @@ extern "C" int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *
   if (h->algo == 2) return ddrl_fail(DDRL_ESTATE, "a policies-only population has no hyper-parameters");
   if (k == "alpha_a" || k == "alpha_v") {
     for (int g = 0; g < G; ++g) { if (!(v[g] > 0)) return ddrl_fail(DDRL_EINVAL, "%s[%d] <= 0", key, g); f[g] = (float)v[g]; }
+    if (k == "alpha_v" && h->nnets == 3 && (rc = upload_vec(h, h->net[2].d_lr, f))) return rc;   // qnn2 is built with alpha_v too
     return upload_vec(h, k == "alpha_a" ? h->net[0].d_lr : h->net[1].d_lr, f);
   }
   if (k == "tau_soft_update") {
@@ -362,7 +404,12 @@ extern "C" int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *
     return upload_vec(h, h->d_omtau, om);
   }
   if (k == "gamma") { for (int g = 0; g < G; ++g) f[g] = (float)v[g]; return upload_vec(h, h->d_gamma, f); }
-  if (k == "decay_v") { DDPG_ONLY(h); for (int g = 0; g < G; ++g) f[g] = (float)v[g]; return upload_vec(h, h->net[1].d_decay, f); }
+  if (k == "decay_v") {
+    DDPG_ONLY(h);
+    for (int g = 0; g < G; ++g) f[g] = (float)v[g];
+    if (h->nnets == 3 && (rc = upload_vec(h, h->net[2].d_decay, f))) return rc;
+    return upload_vec(h, h->net[1].d_decay, f);
+  }
   return ddrl_fail(DDRL_EINVAL, "unknown hyper-parameter '%s'", key);
 }
 
@@ -386,7 +433,7 @@ extern "C" int ddrl_pop_get_weights(ddrl_pop_t *h, int net, double *flat) {
 }
 
 extern "C" int ddrl_pop_get_adam(ddrl_pop_t *h, int net, double *m, double *v, int32_t *iter) {
-  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC) || h->algo == 2) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic of a learning population only");
+  if (!h || !trainable_net(h, net) || h->algo == 2) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic(s) of a learning population only");
   int rc = set_device(h);
   if (rc) return rc;
   TrainNet *t = train_net(h, net);
@@ -400,7 +447,7 @@ extern "C" int ddrl_pop_get_adam(ddrl_pop_t *h, int net, double *m, double *v, i
 }
 
 extern "C" int ddrl_pop_set_adam(ddrl_pop_t *h, int net, const double *m, const double *v, const int32_t *iter) {
-  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC) || h->algo == 2) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic of a learning population only");
+  if (!h || !trainable_net(h, net) || h->algo == 2) return ddrl_fail(DDRL_EINVAL, "Adam state exists for the actor and critic(s) of a learning population only");
   int rc = set_device(h);
   if (rc) return rc;
   TrainNet *t = train_net(h, net);
@@ -543,6 +590,7 @@ extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float
 // (device draws).  The one-tile kernel runs them in ONE launch; the chunked / layer-by-layer paths
 // launch n times.
 static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *mask) {
+  if (h->nnets == 3) return ddrl_fail(DDRL_ESTATE, "a TD3 population is updated with ddrl_pop_td3_update");
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, B = h->cfg.mini_batch_size;
@@ -619,6 +667,90 @@ extern "C" int ddrl_pop_ddpg_update_n(ddrl_pop_t *h, int n, const int32_t *idx, 
   return ddpg_update_n(h, n, idx, mask);
 }
 
+// TD3Ag's end_episode (TD3Ag.hpp:284-380) for every (masked) agent: one launch of the fused kernel
+extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const float *noise, const uint8_t *actor_step,
+                                   const uint8_t *mask) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  DDPG_ONLY(h);
+  if (h->nnets != 3) return ddrl_fail(DDRL_ESTATE, "not a TD3 population (ddrl_td3_create)");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;
+  const uint8_t *dmask;
+  if ((rc = upload_mask(h, mask, &dmask))) return rc;
+  if (idx) {
+    for (int g = 0; g < G; ++g) {
+      if (mask && !mask[g]) continue;
+      if (h->h_len[g] < 250 || h->h_len[g] < B) continue;
+      for (int i = 0; i < B; ++i)
+        if (idx[(size_t)g * B + i] < 0 || idx[(size_t)g * B + i] >= h->h_len[g])
+          return ddrl_fail(DDRL_EINVAL, "idx[%d][%d]=%d outside the replay of %d samples", g, i, idx[(size_t)g * B + i], h->h_len[g]);
+    }
+    HIPCHK(hipMemcpyAsync(h->d_idx, idx, (size_t)G * B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  if (noise) HIPCHK(hipMemcpyAsync(h->d_noise, noise, (size_t)G * B * A * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (actor_step) HIPCHK(hipMemcpyAsync(h->d_astep, actor_step, (size_t)G, hipMemcpyHostToDevice, h->stream));
+  DdpgParams &P = h->P;
+  P.mask = dmask;
+  P.sgate = h->gates_on ? h->d_sgate : nullptr;
+  P.agate = h->gates_on ? h->d_agate : nullptr;
+  P.sa = h->net[0].st; P.sq = h->net[1].st; P.sq2 = h->net[2].st;
+  P.actor_step = actor_step ? h->d_astep : nullptr;
+  P.nupd = 1;
+  P.inverting = 0;
+  HIPCHK(replay_draw_launch(h->d_mt, h->d_mtpos, h->d_len, G, B, 1, dmask, h->d_idx, idx ? 0 : 1, h->beta1, h->beta2,
+                            h->net[0].d_lr, h->net[1].d_lr, h->net[0].st.iter, h->net[1].st.iter,
+                            h->net[0].st.lr_t, h->net[1].st.lr_t, P.upd_done, h->stream));
+  HIPCHK(td3_prep_launch(h->d_nseed, h->d_ncount, h->d_len, G, B, A, dmask, h->d_noise, noise ? 0 : 1,
+                         (float)h->cfg.policy_noise, (float)h->cfg.noise_clip, h->beta1, h->beta2, h->net[2].d_lr,
+                         h->net[2].st.iter, h->net[2].st.lr_t, h->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling) {
+    if (h->ev_used == h->ev_pool.size()) {
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      h->ev_pool.emplace_back(e0, e1);
+    }
+    e0 = h->ev_pool[h->ev_used].first; e1 = h->ev_pool[h->ev_used].second;
+    h->ev_used++;
+    HIPCHK(hipEventRecord(e0, h->stream));
+  }
+  HIPCHK(td3_update_launch(&P, h->force_generic, h->stream));
+  if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
+  if (idx || mask || noise || actor_step) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_td3_seed_noise(ddrl_pop_t *h, const uint64_t *seeds) {
+  if (!h || !seeds) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  if (h->nnets != 3) return ddrl_fail(DDRL_ESTATE, "not a TD3 population");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->d_nseed, seeds, h->G * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_ncount, 0, h->G * sizeof(uint32_t), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_td3_last(ddrl_pop_t *h, float *loss2, float *noise) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  if (h->nnets != 3) return ddrl_fail(DDRL_ESTATE, "not a TD3 population");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const size_t G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;
+  if (loss2) HIPCHK(hipMemcpyAsync(loss2, h->d_loss2, G * 4, hipMemcpyDeviceToHost, h->stream));
+  if (noise) HIPCHK(hipMemcpyAsync(noise, h->d_noise, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_td3_create(const ddrl_ddpg_config *cfg, uint64_t init_seed, ddrl_pop_t **out) {
+  if (!cfg || !out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  ddrl_ddpg_config c = *cfg;
+  c.td3 = 1;
+  return ddrl_ddpg_create(&c, init_seed, out);
+}
+
 extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *qt, float *dact) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   DDPG_ONLY(h);
@@ -680,7 +812,7 @@ extern "C" int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score, co
   if (!h || !score) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   int rc = set_device(h);
   if (rc) return rc;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < h->nnets; ++k) {
     TrainNet &t = h->net[k];
     if (!t.ewc.enabled) continue;
     std::vector<uint8_t> flag(h->G, 0);
@@ -738,13 +870,13 @@ extern "C" int ddrl_pop_ewc_setup(ddrl_pop_t *h, const uint8_t *mask) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   int rc = set_device(h);
   if (rc) return rc;
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < h->nnets; ++k)
     if ((rc = ewc_setup_one(h, h->net[k], mask))) return rc;
   return DDRL_OK;
 }
 
 extern "C" int ddrl_pop_ewc_setup_net(ddrl_pop_t *h, int net, const uint8_t *mask) {
-  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  if (!h || !trainable_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   int rc = set_device(h);
   if (rc) return rc;
   return ewc_setup_one(h, *train_net(h, net), mask);
@@ -754,7 +886,7 @@ extern "C" int ddrl_pop_ewc_decay_update(ddrl_pop_t *h, const uint8_t *mask) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   int rc = set_device(h);
   if (rc) return rc;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < h->nnets; ++k) {
     TrainNet &t = h->net[k];
     if (!t.ewc.enabled || !(h->cfg.ewc_decay >= 0.)) continue;   // DODevMLP.hpp:709-712
     for (int g = 0; g < h->G; ++g)
@@ -765,7 +897,7 @@ extern "C" int ddrl_pop_ewc_decay_update(ddrl_pop_t *h, const uint8_t *mask) {
 }
 
 extern "C" int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost) {
-  if (!h || !cost || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  if (!h || !cost || !trainable_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   int rc = set_device(h);
   if (rc) return rc;
   TrainNet &t = *train_net(h, net);
@@ -785,7 +917,7 @@ extern "C" int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost) {
 
 extern "C" int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *fisher_hat, double *wstar,
                                 double *fisher_nbr, double *decay_mult) {
-  if (!h || (net != DDRL_NET_ACTOR && net != DDRL_NET_CRITIC)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  if (!h || !trainable_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   int rc = set_device(h);
   if (rc) return rc;
   TrainNet &t = *train_net(h, net);

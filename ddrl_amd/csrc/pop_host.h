@@ -39,7 +39,13 @@ struct ddrl_pop {
   ddrl_ddpg_config cfg;            // NFAC handles fill the fields the shared entry points read
   int G = 0, device = 0;
   hipStream_t stream = nullptr;
-  TrainNet net[2];                 // 0 actor, 1 critic  (targets hang off st.wt)
+  TrainNet net[3];                 // 0 actor, 1 critic, 2 second critic (TD3)  (targets hang off st.wt)
+  int nnets = 2;
+  // TD3: smoothing-noise streams and staging
+  uint64_t *d_nseed = nullptr;
+  uint32_t *d_ncount = nullptr;
+  float *d_noise = nullptr, *d_loss2 = nullptr;
+  uint8_t *d_astep = nullptr;
   // replay
   int rowlen = 0;
   float *d_rep = nullptr;
@@ -165,10 +171,17 @@ static int set_device(ddrl_pop *h) {
   return DDRL_OK;
 }
 
-static TrainNet *train_net(ddrl_pop *h, int net) { return (net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET) ? &h->net[0] : &h->net[1]; }
+static TrainNet *train_net(ddrl_pop *h, int net) {
+  if (net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET) return &h->net[0];
+  return (net == DDRL_NET_CRITIC2 || net == DDRL_NET_CRITIC2_TARGET) ? &h->net[2] : &h->net[1];
+}
 static float *net_weights(ddrl_pop *h, int net) {
   TrainNet *t = train_net(h, net);
-  return (net == DDRL_NET_ACTOR || net == DDRL_NET_CRITIC) ? t->st.w : t->st.wt;
+  return (net == DDRL_NET_ACTOR || net == DDRL_NET_CRITIC || net == DDRL_NET_CRITIC2) ? t->st.w : t->st.wt;
+}
+// nets with an optimiser (Adam state, EWC arrays)
+static bool trainable_net(ddrl_pop *h, int net) {
+  return net == DDRL_NET_ACTOR || net == DDRL_NET_CRITIC || (net == DDRL_NET_CRITIC2 && h->nnets == 3);
 }
 
 static int refresh_ewc_coef(ddrl_pop *h, TrainNet &t) {
@@ -214,6 +227,9 @@ static int alloc_net(ddrl_pop *h, TrainNet &t, bool ewc, bool target = true) {
 
 
 // NFAC populations have no target nets (OfflineCaclaAg.hpp:186-196)
-static bool bad_net(ddrl_pop *h, int net) { return net < 0 || net > 3 || (h->algo == 1 && net > DDRL_NET_CRITIC) || (h->algo == 2 && net != DDRL_NET_ACTOR); }
+static bool bad_net(ddrl_pop *h, int net) {
+  return net < 0 || net > DDRL_NET_CRITIC2_TARGET || (net > DDRL_NET_CRITIC_TARGET && h->nnets < 3) ||
+         (h->algo == 1 && net > DDRL_NET_CRITIC) || (h->algo == 2 && net != DDRL_NET_ACTOR);
+}
 #define DDPG_ONLY(h) do { if ((h)->algo != 0) return ddrl_fail(DDRL_ESTATE, "%s: DDPG populations only", __func__); } while (0)
 

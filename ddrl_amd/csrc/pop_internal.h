@@ -137,6 +137,11 @@ struct DdpgParams {
   // nets wider than DDRL_MAXW (kernels_ddpg_wide.hip): activation tiles in HBM, [G x maxchunks x wide_stride]
   float *wide;
   size_t wide_stride;
+  // TD3 (kernels_td3.hip): second critic, target-policy smoothing draws, delayed actor update
+  NetState sq2;
+  const float *noise;       // [G x B x A]
+  const uint8_t *actor_step;   // [G] or null (= every agent's actor is updated)
+  float *loss2_out;         // [G]
   int nupd;                 // consecutive updates per launch (>= 1): idx is [G x nupd x B], lr_t [G x nupd]
   int *upd_done;            // [G] updates of this launch an agent has completed (zeroed by the prep kernel)
   int *upd_error;           // [1] raised when a workgroup gave up waiting for its predecessor

@@ -32,6 +32,7 @@ class DdpgConfigC(C.Structure):
         ("ewc", C.c_double), ("ewc_decay", C.c_double), ("ewc_fisher_beta", C.c_double),
         ("ewc_best_param_method", C.c_int), ("ewc_for_critic", C.c_int),
         ("device", C.c_int),
+        ("td3", C.c_int), ("policy_freq", C.c_int), ("policy_noise", C.c_double), ("noise_clip", C.c_double),
     ]
 
 
@@ -78,6 +79,12 @@ SYMBOLS = [
     ("ddrl_pop_ddpg_update", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ddpg_update_n", _i, [_vp, _i, _vp, _vp]),
     ("ddrl_pop_ddpg_last", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_td3_config_from_ini", _i, [_cp, C.POINTER(DdpgConfigC)]),
+    ("ddrl_td3_create", _i, [C.POINTER(DdpgConfigC), C.c_uint64, C.POINTER(_vp)]),
+    ("ddrl_pop_td3_seed_noise", _i, [_vp, _vp]),
+    ("ddrl_pop_td3_update", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_pop_td3_last", _i, [_vp, _vp, _vp]),
+    ("ddrl_agents_create_td3", _i, [_cp, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
     ("ddrl_pop_set_gates", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_get_gates", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_ewc_setup_net", _i, [_vp, _i, _vp]),
@@ -124,6 +131,16 @@ SYMBOLS = [
     ("OfflineCaclaAg_save", None, [C.c_int64, _i]),
     ("OfflineCaclaAg_load", None, [C.c_int64, _i]),
     ("OfflineCaclaAg_delete", None, [C.c_int64]),
+    ("TD3Ag_new", C.c_int64, [C.c_uint, C.c_uint]),
+    ("TD3Ag_unique_invoke", None, [C.c_int64, _i, C.POINTER(_cp)]),
+    ("TD3Ag_start_episode", None, [C.c_int64, _vp, C.c_bool]),
+    ("TD3Ag_run", _vp, [C.c_int64, C.c_double, _vp, C.c_bool, C.c_bool, C.c_bool]),
+    ("TD3Ag_end_episode", None, [C.c_int64, C.c_bool]),
+    ("TD3Ag_dump", None, [C.c_int64, C.c_bool, _i, _i, C.c_double]),
+    ("TD3Ag_display", None, [C.c_int64, C.c_bool, _i, _i, C.c_double]),
+    ("TD3Ag_save", None, [C.c_int64, _i]),
+    ("TD3Ag_load", None, [C.c_int64, _i]),
+    ("TD3Ag_delete", None, [C.c_int64]),
     ("ddrl_nfac_config_default", _i, [C.POINTER(NfacConfigC)]),
     ("ddrl_nfac_config_from_ini", _i, [_cp, C.POINTER(NfacConfigC)]),
     ("ddrl_nfac_create", _i, [C.POINTER(NfacConfigC), C.c_uint64, C.POINTER(_vp)]),

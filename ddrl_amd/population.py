@@ -11,6 +11,7 @@ import numpy as np
 from . import lib as _l
 
 NET_ACTOR, NET_CRITIC, NET_ACTOR_TARGET, NET_CRITIC_TARGET = 0, 1, 2, 3
+NET_CRITIC2, NET_CRITIC2_TARGET = 4, 5      # TD3 populations only
 
 
 def _p(a):
@@ -27,10 +28,12 @@ class DdpgConfig:
             self.set(k, v)
 
     @classmethod
-    def from_ini(cls, path, n_agents=1, nb_sensors=0, nb_motors=0):
+    def from_ini(cls, path, n_agents=1, nb_sensors=0, nb_motors=0, td3=False):
+        """td3: read TD3Ag's keys (TD3Ag.hpp:165-186) instead of DeepQNAg's"""
         o = cls()
         o.c.n_agents, o.c.nb_sensors, o.c.nb_motors = n_agents, nb_sensors, nb_motors
-        _l.check(_l.load().ddrl_ddpg_config_from_ini(path.encode(), C.byref(o.c)))
+        f = _l.load().ddrl_td3_config_from_ini if td3 else _l.load().ddrl_ddpg_config_from_ini
+        _l.check(f(path.encode(), C.byref(o.c)))
         return o
 
     def set(self, k, v):
@@ -222,6 +225,41 @@ class DdpgPopulation(Population):
 
     def set_option(self, key, value):
         _l.check(self.L.ddrl_pop_set_option(self.h, key.encode(), int(value)))
+
+
+class Td3Population(DdpgPopulation):
+    """G independent TD3 agents on one GPU (TD3Ag.hpp's DeepQNAg<MLP> x G): six nets per agent."""
+
+    def __init__(self, cfg, init_seed=0):
+        self.L = _l.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        _l.check(self.L.ddrl_td3_create(C.byref(cfg.c), init_seed, C.byref(h)))
+        self.h = h
+        self.G, self.S, self.A, self.B = cfg.c.n_agents, cfg.c.nb_sensors, cfg.c.nb_motors, cfg.c.mini_batch_size
+
+    def seed_noise(self, seeds):
+        s = np.ascontiguousarray(seeds, np.uint64).reshape(self.G)
+        _l.check(self.L.ddrl_pop_td3_seed_noise(self.h, _p(s)))
+
+    # TD3Ag::end_episode for every (masked) agent; noise [G x B x A] or None (device draws)
+    def update(self, idx=None, noise=None, actor_step=None, mask=None):
+        i = None if idx is None else np.ascontiguousarray(idx, np.int32).reshape(self.G, self.B)
+        nz = None if noise is None else np.ascontiguousarray(noise, np.float32).reshape(self.G, self.B, self.A)
+        st = None if actor_step is None else np.ascontiguousarray(np.broadcast_to(np.asarray(actor_step, np.uint8), (self.G,)))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_td3_update(self.h, _p(i), _p(nz), _p(st), _p(m)))
+
+    def update_n(self, n, idx=None, mask=None):
+        raise _l.DdrlError(-3, "TD3Ag has no fupd loop: one update per stored transition")
+
+    def last(self):
+        d = DdpgPopulation.last(self)
+        loss2 = np.empty(self.G, np.float32)
+        nz = np.empty((self.G, self.B, self.A), np.float32)
+        _l.check(self.L.ddrl_pop_td3_last(self.h, _p(loss2), _p(nz)))
+        d.update(loss2=loss2, noise=nz)
+        return d
 
 
 class NfacConfig:

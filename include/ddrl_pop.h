@@ -41,6 +41,9 @@ extern "C" {
 #define DDRL_NET_CRITIC         1
 #define DDRL_NET_ACTOR_TARGET   2
 #define DDRL_NET_CRITIC_TARGET  3
+/* TD3 populations only (TD3Ag.hpp:221-229): qnn2, qnn_target2 */
+#define DDRL_NET_CRITIC2         4
+#define DDRL_NET_CRITIC2_TARGET  5
 
 typedef struct ddrl_pop ddrl_pop_t;
 
@@ -67,6 +70,10 @@ typedef struct {
   double ewc, ewc_decay, ewc_fisher_beta;
   int    ewc_best_param_method, ewc_for_critic;
   int    device;                   /* HIP device ordinal; -1 = current */
+  /* TD3Ag (agent/deepqn/include/TD3Ag.hpp:183-186); td3 == 0: a DDPG population, the rest unused */
+  int    td3;
+  int    policy_freq;              /* agent.policy_freq: the actor and the targets move every policy_freq-th step */
+  double policy_noise, noise_clip; /* agent.policy_noise, agent.noise_clip: target-policy smoothing */
 } ddrl_ddpg_config;
 
 const char *ddrl_last_error(void);
@@ -140,6 +147,30 @@ int ddrl_pop_ddpg_update(ddrl_pop_t *h, const int32_t *idx, const uint8_t *mask)
  * stream and same results as n calls of ddrl_pop_ddpg_update.  idx: NULL or [G x n x B].
  * 1 <= n <= 64. */
 int ddrl_pop_ddpg_update_n(ddrl_pop_t *h, int n, const int32_t *idx, const uint8_t *mask);
+/* ---- TD3 (the reference ships it as libddrl-td3: ddpg.cpp built with WANT_TD3) ----
+ * ddrl_td3_config_from_ini reads the keys TD3Ag's _unique_invoke reads (TD3Ag.hpp:165-186: DeepQNAg's
+ * without inverting_grad / force_more_update / nstep_return, plus policy_noise, noise_clip,
+ * policy_freq) and sets td3 = 1; ddrl_td3_create = ddrl_ddpg_create on such a config: six nets per
+ * agent (ann, qnn, qnn2 and their targets, TD3Ag.hpp:208-230).  This round: one-tile minibatches
+ * (mini_batch_size <= 64) and layers up to 128 wide.  Every other ddrl_pop_* entry point applies
+ * (alpha_v / decay_v set both critics; the EWC calls cover qnn2 like qnn). */
+int ddrl_td3_config_from_ini(const char *path, ddrl_ddpg_config *cfg);
+int ddrl_td3_create(const ddrl_ddpg_config *cfg, uint64_t init_seed, ddrl_pop_t **out);
+/* seeds of the target-policy smoothing streams, one per agent (default: derived from init_seed) */
+int ddrl_pop_td3_seed_noise(ddrl_pop_t *h, const uint64_t *seeds /* [G] */);
+/* One call of TD3Ag's end_episode (TD3Ag.hpp:284-380) for every agent with mask[g] != 0: sample B
+ * indices, a' = clip(ann_target(s') + eps, -1, 1), y = r + gamma min(Q1', Q2'), both critics' Adam
+ * steps, and for agents with actor_step[g] != 0 (current_step_counter % policy_freq == 0, :333; NULL
+ * = all) the actor's step through the first critic and the three soft target updates.
+ * idx as in ddrl_pop_ddpg_update.  noise: NULL = drawn on the device (N(0, policy_noise) truncated to
+ * +-noise_clip, own stream: the reference's comes from its clock-seeded engine), else host array
+ * [G x B x A] of the smoothing draws (parity tests). */
+int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const float *noise, const uint8_t *actor_step,
+                        const uint8_t *mask);
+/* diagnostics of the last TD3 update beyond ddrl_pop_ddpg_last (which applies): the second critic's
+ * loss [G] and the smoothing noise used [G x B x A].  Either may be NULL. */
+int ddrl_pop_td3_last(ddrl_pop_t *h, float *loss2, float *noise);
+
 /* diagnostics of the last update: indices used [G x B], critic loss [G], TD targets [G x B],
  * action gradients fed to the actor [G x B x A].  Any pointer may be NULL. */
 int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *q_targets, float *dact);
@@ -186,6 +217,11 @@ int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int nb_sensors, 
  * max_trajectory <= 0: sized from environment.max_step_per_instance when the ini has it. */
 int ddrl_agents_create_nfac(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int max_trajectory,
                             int device, uint64_t seed, ddrl_agents_t **out);
+/* TD3Ag (agent/deepqn/include/TD3Ag.hpp:95-98, 165-231; start/run/end as DeepQNAg's): one update per
+ * stored transition (:156-163), the actor and targets every policy_freq-th step of the episode (:333),
+ * one more update at the end of a learning episode, end_instance counts the episode (:278-282). */
+int ddrl_agents_create_td3(const char *ini_path, int n_agents, int nb_sensors, int nb_motors, int device,
+                           uint64_t seed, ddrl_agents_t **out);
 int ddrl_agents_destroy(ddrl_agents_t *h);
 /* DODevMLP's developmental schedule: when the ini has a [devnn] section with st_control, the DDPG and
  * NFAC front ends read DODevMLP::exploit's keys (DODevMLP.hpp:76-214: st/ac_control, heuristic = 1 with
@@ -237,6 +273,19 @@ void OfflineCaclaAg_display(int64_t ag, bool learning, int episode, int step, do
 void OfflineCaclaAg_save(int64_t ag, int episode);
 void OfflineCaclaAg_load(int64_t ag, int episode);
 void OfflineCaclaAg_delete(int64_t ag);
+/* TD3: the reference compiles ddpg.cpp with WANT_TD3 into libddrl-td3, which exports the DDPGAg_* names
+ * over TD3Ag (ddpg.cpp:3-5; agent/deepqn/CMakeLists.txt:84-88; caller gym/agent.py:112-157).  One
+ * library cannot export a name twice: the same calls under the TD3Ag_ prefix. */
+int64_t TD3Ag_new(unsigned nb_motors, unsigned nb_sensors);
+void TD3Ag_unique_invoke(int64_t ag, int argc, char **argv);
+void TD3Ag_start_episode(int64_t ag, const double *state, bool learning);
+const double *TD3Ag_run(int64_t ag, double reward, const double *sensors, bool learning, bool goal_reached, bool last);
+void TD3Ag_end_episode(int64_t ag, bool learning);
+void TD3Ag_dump(int64_t ag, bool learning, int episode, int step, double treward);
+void TD3Ag_display(int64_t ag, bool learning, int episode, int step, double treward);
+void TD3Ag_save(int64_t ag, int episode);
+void TD3Ag_load(int64_t ag, int episode);
+void TD3Ag_delete(int64_t ag);
 
 /* ------------------------------------------------------------------------------------------------
  * NFAC(lambda)-V (agent/cacla/include/OfflineCaclaAg.hpp): population of G independent agents,

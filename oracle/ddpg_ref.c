@@ -12,15 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-struct ora_ddpg {
-  ora_ddpg_cfg c;
-  ora_mlp *ann, *qnn, *ann_target, *qnn_target;
-  ora_mt19937 eng;
-  /* ring replay */
-  int len, head, row;            /* row = 2S + 2A + 2 : s, pure_a(unused here), a, s2, r, goal */
-  double *rep;
-  double *last_qt, *last_dact;
-};
+#include "ddpg_ref.h"
 
 ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c) {
   ora_ddpg *d = (ora_ddpg *)calloc(1, sizeof(ora_ddpg));
@@ -45,6 +37,12 @@ ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c) {
   }
   d->ann_target = ora_mlp_clone(d->ann);   /* DeepQNAg.hpp:216-219 */
   d->qnn_target = ora_mlp_clone(d->qnn);   /* DeepQNAg.hpp:231-234 */
+  if (c->td3) {                            /* TD3Ag.hpp:221-229: a second critic of the same shape and its target */
+    d->qnn2 = ora_mlp_create(c->n_hidden_q + 1, dims, c->hidden_act, 0, c->alpha_v, c->momentum, c->decay_v);
+    if (c->ewc >= 0. && c->ewc_for_critic >= 1)
+      ora_mlp_ewc_config(d->qnn2, c->ewc, c->ewc_decay, c->ewc_fisher_beta, c->ewc_best_method);
+    d->qnn_target2 = ora_mlp_clone(d->qnn2);
+  }
   ora_mt_seed(&d->eng, c->seed);
   d->row = 2 * c->S + 2 * c->A + 2;
   d->rep = (double *)calloc((size_t)c->replay_cap * d->row, sizeof(double));
@@ -56,18 +54,19 @@ ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c) {
 void ora_ddpg_free(ora_ddpg *d) {
   if (!d) return;
   ora_mlp_free(d->ann); ora_mlp_free(d->qnn); ora_mlp_free(d->ann_target); ora_mlp_free(d->qnn_target);
+  if (d->qnn2) { ora_mlp_free(d->qnn2); ora_mlp_free(d->qnn_target2); }
   free(d->rep); free(d->last_qt); free(d->last_dact); free(d);
 }
 
 ora_mlp *ora_ddpg_net(ora_ddpg *d, int which) {
-  switch (which) { case 0: return d->ann; case 1: return d->qnn; case 2: return d->ann_target; default: return d->qnn_target; }
+  switch (which) {
+    case 0: return d->ann; case 1: return d->qnn; case 2: return d->ann_target; case 3: return d->qnn_target;
+    case 4: return d->qnn2; default: return d->qnn_target2;
+  }
 }
 
 /* target nets were cloned at creation; after set_weights on ann/qnn the test re-syncs explicitly */
 
-static double *rep_row(const ora_ddpg *d, int logical) {
-  return d->rep + (size_t)((d->head + logical) % d->c.replay_cap) * d->row;
-}
 
 /* DeepQNAg::insertSample (DeepQNAg.hpp:159-165) without the trailing end_episode(true) */
 void ora_ddpg_insert(ora_ddpg *d, const double *s, const double *a, double r, const double *s2, int goal) {

@@ -80,10 +80,11 @@ typedef struct {
   double ewc, ewc_decay, ewc_fisher_beta;   /* ewc<0 => disabled */
   int ewc_for_critic, ewc_best_method;
   uint32_t seed;                            /* replay sampling engine seed */
+  int td3;                                  /* TD3Ag: second critic pair (qnn2, qnn_target2) */
 } ora_ddpg_cfg;
 ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c);
 void   ora_ddpg_free(ora_ddpg *d);
-ora_mlp *ora_ddpg_net(ora_ddpg *d, int which);   /* 0 ann 1 qnn 2 ann_target 3 qnn_target */
+ora_mlp *ora_ddpg_net(ora_ddpg *d, int which);   /* 0 ann 1 qnn 2 ann_target 3 qnn_target 4 qnn2 5 qnn_target2 (td3) */
 void   ora_ddpg_insert(ora_ddpg *d, const double *s, const double *a, double r,
                        const double *s2, int goal);          /* ring push, no update */
 int    ora_ddpg_replay_len(const ora_ddpg *d);
@@ -93,6 +94,12 @@ double ora_ddpg_update(ora_ddpg *d, const int *idx, int *idx_out);
 void   ora_ddpg_ewc_setup(ora_ddpg *d);
 /* diagnostics of the last update */
 void   ora_ddpg_last(const ora_ddpg *d, double *q_targets, double *actor_dact);
+
+/* TD3 (td3_ref.c): TD3Ag::end_episode (agent/deepqn/include/TD3Ag.hpp:284-380) on a ddpg object created
+ * with td3 = 1.  noise [B x A]: the target-policy smoothing draws (:307; the reference takes them from its
+ * clock-seeded engine, so the caller supplies them).  actor_step: current_step_counter % policy_freq == 0
+ * (:333).  Returns the first critic's loss; *loss2 (may be NULL) the second's. */
+double ora_td3_update(ora_ddpg *d, const int *idx, int *idx_out, const double *noise, int actor_step, double *loss2);
 
 /* ---- NFAC(lambda)-V (nfac_ref.c) ---- */
 typedef struct {

@@ -33,7 +33,7 @@ class DdpgCfg(C.Structure):
         ("decay_v", C.c_double),
         ("ewc", C.c_double), ("ewc_decay", C.c_double), ("ewc_fisher_beta", C.c_double),
         ("ewc_for_critic", C.c_int), ("ewc_best_method", C.c_int),
-        ("seed", C.c_uint32),
+        ("seed", C.c_uint32), ("td3", C.c_int),
     ]
 
 
@@ -112,6 +112,8 @@ def lib():
     L.ora_ddpg_update.argtypes = [vp, vp, vp]
     L.ora_ddpg_ewc_setup.argtypes = [vp]
     L.ora_ddpg_last.argtypes = [vp, vp, vp]
+    L.ora_td3_update.restype = C.c_double
+    L.ora_td3_update.argtypes = [vp, vp, vp, _dp, C.c_int, vp]
     L.ora_nfac_create.restype = vp
     L.ora_nfac_create.argtypes = [C.POINTER(NfacCfg)]
     L.ora_nfac_free.argtypes = [vp]
@@ -268,8 +270,9 @@ class Ddpg:
     def __init__(self, S, A, B, hidden_a, hidden_q, replay_cap=10000, hidden_act=1, actor_out_act=2,
                  momentum=0, inverting_grad=True, nstep_return=0, gamma=0.99, tau=0.001, alpha_a=1e-4,
                  alpha_v=1e-3, decay_v=-1.0, ewc=-1.0, ewc_decay=-1.0, ewc_fisher_beta=0.999,
-                 ewc_for_critic=0, ewc_best_method=0, seed=0):
+                 ewc_for_critic=0, ewc_best_method=0, seed=0, td3=False):
         c = DdpgCfg()
+        c.td3 = int(td3)
         c.S, c.A, c.B, c.replay_cap = S, A, B, replay_cap
         c.n_hidden_a = len(hidden_a); _fill_hidden(c.hidden_a, hidden_a)
         c.n_hidden_q = len(hidden_q); _fill_hidden(c.hidden_q, hidden_q)
@@ -284,7 +287,7 @@ class Ddpg:
         da = [S] + list(hidden_a) + [A]
         dq = [S + A] + list(hidden_q) + [1]
         self.nets = [Mlp(d, _h=lib().ora_ddpg_net(self.h, i), _own=False)
-                     for i, d in enumerate([da, dq, da, dq])]
+                     for i, d in enumerate([da, dq, da, dq] + ([dq, dq] if td3 else []))]
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -299,6 +302,19 @@ class Ddpg:
     def ann_target(self): return self.nets[2]
     @property
     def qnn_target(self): return self.nets[3]
+    @property
+    def qnn2(self): return self.nets[4]
+    @property
+    def qnn_target2(self): return self.nets[5]
+
+    def update_td3(self, noise, actor_step=True, idx=None):
+        """TD3Ag::end_episode; noise [B x A] = the target-policy smoothing draws.  -> (loss1, loss2, idx)"""
+        out = np.empty(self.B, dtype=np.int32)
+        i = None if idx is None else np.ascontiguousarray(idx, dtype=np.int32)
+        nz = np.ascontiguousarray(noise, np.float64).reshape(self.B * self.A)
+        l2 = C.c_double()
+        loss = lib().ora_td3_update(self.h, _vp(i), _vp(out), nz, int(actor_step), C.cast(C.byref(l2), C.c_void_p))
+        return loss, l2.value, out
 
     def insert(self, s, a, r, s2, goal):
         lib().ora_ddpg_insert(self.h, np.ascontiguousarray(s, np.float64), np.ascontiguousarray(a, np.float64),

@@ -14,7 +14,7 @@ HAVE_GPU = os.path.exists("/dev/kfd")
 def _declared():
     txt = open(os.path.join(ROOT, "include", "ddrl_pop.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(ddrl_[a-z0-9_]+|DDPGAg_[a-z_]+|OfflineCaclaAg_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(ddrl_[a-z0-9_]+|DDPGAg_[a-z_]+|OfflineCaclaAg_[a-z_]+|TD3Ag_[a-z_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -80,6 +80,30 @@ ewc_for_critic=1
     assert "hidden_unit_q" in str(e.value)
     with pytest.raises(ddrl_amd.DdrlError):
         ddrl_amd.DdpgConfig.from_ini(str(tmp_path / "nope.ini"))
+
+
+def test_td3_ini_keys(tmp_path):
+    """TD3Ag::_unique_invoke (TD3Ag.hpp:165-186) reads DeepQNAg's keys without inverting_grad /
+    force_more_update / nstep_return, plus policy_noise, noise_clip, policy_freq"""
+    import ddrl_amd
+    base = ("[agent]\ngamma=0.9\ndecision_each=1\nnoise=0.1\ngaussian_policy=1\nhidden_unit_q=8:6\nhidden_unit_a=8\n"
+            "mini_batch_size=16\nreplay_memory=300\ntau_soft_update=0.01\nalpha_a=0.001\nalpha_v=0.002\ndecay_v=-1\n"
+            "batch_norm_critic=0\nbatch_norm_actor=0\nactor_output_layer_type=2\nhidden_layer_type=1\ntest_net=false\n"
+            "bn_adapt=false\nmomentum=0\n")
+    p = tmp_path / "td3.ini"
+    p.write_text(base + "policy_noise=0.25\nnoise_clip=0.4\npolicy_freq=3\n")
+    c = ddrl_amd.DdpgConfig.from_ini(str(p), n_agents=2, nb_sensors=4, nb_motors=1, td3=True)
+    assert c.get("td3") == 1 and c.get("policy_freq") == 3 and c.get("policy_noise") == 0.25 and c.get("noise_clip") == 0.4
+    assert c.get("hidden_unit_q") == [8, 6] and c.get("inverting_grad") == 0 and c.get("force_more_update") == 0
+    with pytest.raises(ddrl_amd.DdrlError, match="inverting_grad"):      # the same file is not a DDPG ini
+        ddrl_amd.DdpgConfig.from_ini(str(p))
+    p.write_text(base + "policy_noise=0.25\nnoise_clip=0.4\n")
+    with pytest.raises(ddrl_amd.DdrlError, match="policy_freq"):
+        ddrl_amd.DdpgConfig.from_ini(str(p), td3=True)
+    assert ddrl_amd.DdpgConfig().get("td3") == 0
+    if not HAVE_GPU:
+        with pytest.raises(ddrl_amd.DdrlError, match="no HIP device"):
+            ddrl_amd.Td3Population(ddrl_amd.DdpgConfig(n_agents=2, td3=1, inverting_grad=0))
 
 
 def test_no_cpu_fallback():

@@ -8,6 +8,10 @@
 //           segment  -> 16 rows x 64 B per wave instruction
 //   mode 1: two adjacent tiles exchanged between lane pairs (c, c^8): 8 rows x 128 B per instruction
 //   mode 2: flat, 64 lanes x 16 B contiguous = 1 KiB per instruction
+//   mode 3: the seven arrays interleaved per KiB block ([w|m|v|wt|fisher|fhat|wstar] = 7 KiB contiguous
+//           per 256 parameters): does a longer contiguous run per DRAM page visit raise the rate?
+//   mode 4: as mode 2 with two blocks (14 KiB of loads) in flight per wave
+//   mode 5: plain copy, one array read, one written (the ceiling for mixed read / write traffic)
 // usage: membench <mode> [G] [iters]      prints GB/s of algorithmic bytes (48 B per parameter)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -42,6 +46,48 @@ __global__ void __launch_bounds__(256) sweep(const Arrays A) {
     for (int i = tid * 4; i < ROWS * KP; i += 1024) sweep4(A, base + i, true);
     return;
   }
+  if (MODE == 3) {
+    // block b of the agent: floats [b*7*256, (b+1)*7*256) of a[0]; array k of the block at + k*256
+    float *blk = A.a[0] + (size_t)agent * 7 * NP;
+    for (int b = wave; b * 256 < ROWS * KP; b += 4) {
+      float *p = blk + (size_t)b * 7 * 256 + lane * 4;
+      f32x4 r[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) r[k] = *(const f32x4 *)(p + k * 256);
+      f32x4 g = r[5] * (r[0] - r[6]);
+      f32x4 m = 0.1f * g + 0.9f * r[1], v = 0.001f * g * g + 0.999f * r[2];
+      f32x4 w = r[0] - 1e-3f * m / (v + 1e-8f);
+      f32x4 wt = 0.01f * w + 0.99f * r[3], f = r[4] * 0.999f + g * g;
+      *(f32x4 *)(p) = w; *(f32x4 *)(p + 256) = m; *(f32x4 *)(p + 512) = v; *(f32x4 *)(p + 768) = wt; *(f32x4 *)(p + 1024) = f;
+    }
+    return;
+  }
+  if (MODE == 4) {
+    int i = tid * 4;
+    for (; i + 1024 < ROWS * KP; i += 2048) {
+      f32x4 r[14];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { r[k] = *(const f32x4 *)(A.a[k] + base + i); r[7 + k] = *(const f32x4 *)(A.a[k] + base + i + 1024); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 *q = r + 7 * h;
+        f32x4 g = q[5] * (q[0] - q[6]);
+        f32x4 m = 0.1f * g + 0.9f * q[1], v = 0.001f * g * g + 0.999f * q[2];
+        f32x4 w = q[0] - 1e-3f * m / (v + 1e-8f);
+        f32x4 wt = 0.01f * w + 0.99f * q[3], f = q[4] * 0.999f + g * g;
+        const size_t j = base + i + 1024 * h;
+        *(f32x4 *)(A.a[0] + j) = w; *(f32x4 *)(A.a[1] + j) = m; *(f32x4 *)(A.a[2] + j) = v;
+        *(f32x4 *)(A.a[3] + j) = wt; *(f32x4 *)(A.a[4] + j) = f;
+      }
+    }
+    for (; i < ROWS * KP; i += 1024) sweep4(A, base + i, true);
+    return;
+  }
+  if (MODE == 5) {
+    for (int k = 0; k < 6; ++k)     // 6 arrays' worth of bytes copied a[k] -> a[(k+1)%7]: 24 B read + 24 B written per parameter
+      for (int i = tid * 4; i < ROWS * KP; i += 1024) *(f32x4 *)(A.a[6] + base + i) = *(const f32x4 *)(A.a[k] + base + i);
+    return;
+  }
   const int NT = (ROWS + 15) / 16, KT = (KP + 15) / 16;
   if (MODE == 0) {
     for (int p = wave; p < NT * KT; p += 4) {
@@ -70,6 +116,11 @@ int main(int argc, char **argv) {
   const int iters = argc > 3 ? atoi(argv[3]) : 20;
   Arrays A;
   const size_t n = (size_t)G * NP;
+  if (mode == 3) {
+    if (hipMalloc(&A.a[0], n * 4 * 7) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMemset(A.a[0], 0, n * 4 * 7);
+    for (int k = 1; k < 7; ++k) A.a[k] = A.a[0];
+  } else
   for (int k = 0; k < 7; ++k) {
     if (hipMalloc(&A.a[k], n * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(A.a[k], 0, n * 4);
@@ -79,6 +130,9 @@ int main(int argc, char **argv) {
   auto launch = [&]() {
     if (mode == 0) hipLaunchKernelGGL(sweep<0>, dim3(G), dim3(256), 0, 0, A);
     else if (mode == 1) hipLaunchKernelGGL(sweep<1>, dim3(G), dim3(256), 0, 0, A);
+    else if (mode == 3) hipLaunchKernelGGL(sweep<3>, dim3(G), dim3(256), 0, 0, A);
+    else if (mode == 4) hipLaunchKernelGGL(sweep<4>, dim3(G), dim3(256), 0, 0, A);
+    else if (mode == 5) hipLaunchKernelGGL(sweep<5>, dim3(G), dim3(256), 0, 0, A);
     else hipLaunchKernelGGL(sweep<2>, dim3(G), dim3(256), 0, 0, A);
   };
   for (int i = 0; i < 3; ++i) launch();
