@@ -55,6 +55,12 @@ class _Agents:
     def end_episode(self, learning=True, mask=None):
         _l.check(self.L.ddrl_agents_end_episode(self.h, _p(self._flags(learning)), _p(self._mask(mask))))
 
+    def save_run(self, path):
+        _l.check(self.L.ddrl_agents_save_run(self.h, str(path).encode()))
+
+    def load_previous_run(self, path):
+        _l.check(self.L.ddrl_agents_load_previous_run(self.h, str(path).encode()))
+
     def stats(self):
         swr, sr, ep = np.empty(self.G), np.empty(self.G), np.empty(self.G, np.int32)
         _l.check(self.L.ddrl_agents_stats(self.h, _p(swr), _p(sr), _p(ep)))

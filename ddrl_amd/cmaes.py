@@ -88,6 +88,13 @@ class Cmaes:
         _l.check(self._L.ddrl_cmaes_get_vec(self._h, key.encode(), out.ctypes.data))
         return out.reshape(self.N, self.N) if key in ("C", "B") else out
 
+    # cmaes_WriteToFile(evo, "resume", ...) / cmaes_resume_distribution (CMAESAg.hpp:279-308), bit-identical continuation
+    def save_run(self, path):
+        _l.check(self._L.ddrl_cmaes_save_run(self._h, str(path).encode()))
+
+    def load_previous_run(self, path):
+        _l.check(self._L.ddrl_cmaes_load_previous_run(self._h, str(path).encode()))
+
     def set_option(self, key, value):
         _l.check(self._L.ddrl_cmaes_set_option(self._h, key.encode(), int(value)))
 

@@ -10,6 +10,7 @@
 #include "pop_host.h"
 
 #include <memory>
+#include <sstream>
 
 struct AgentState {
   std::vector<double> inter_rewards;
@@ -696,6 +697,78 @@ extern "C" int ddrl_agents_stats(ddrl_agents_t *h, double *sum_weighted_reward, 
   }
   return DDRL_OK;
 }
+
+// ---- run state of the front end: ARLAgent / DeepQNAg / CMAESAg save_run + load_previous_run
+// (DeepQNAg.hpp:504-537: nets, trajectory, episode; CMAESAg.hpp:279-308: scores, counters, the c-cmaes resume
+// file) for all agents in one file, followed by the population's records and the optimiser's ----
+static int agents_checkpoint(ddrl_agents *h, Ckpt &c) {
+  int rc;
+  const int meta[4] = {h->algo, h->G, h->S, h->A};
+  if ((rc = c.same("agents.meta", meta, sizeof(meta)))) return rc;
+  for (int g = 0; g < h->G; ++g) {
+    AgentState &s = h->ag[g];
+    double d[5] = {s.global_pow_gamma, s.sum_weighted_reward, s.sum_reward, s.last_sum_weighted_reward, s.last_receive_reward};
+    int i[6] = {s.time_for_ac, s.last_episode_learning, s.have_last, s.episode, s.step, s.td3_step};
+    std::ostringstream os;
+    os << s.engine;
+    std::string es = os.str();
+    std::vector<char> eng(es.begin(), es.end());
+    if ((rc = c.host("agent.d", d, sizeof(d))) || (rc = c.host("agent.i", i, sizeof(i))) || (rc = c.vec("agent.inter_rewards", s.inter_rewards)) ||
+        (rc = c.vec("agent.ou_x", s.ou_x)) || (rc = c.vec("agent.engine", eng))) return rc;
+    if (!c.writing) {
+      s.global_pow_gamma = d[0]; s.sum_weighted_reward = d[1]; s.sum_reward = d[2]; s.last_sum_weighted_reward = d[3]; s.last_receive_reward = d[4];
+      s.time_for_ac = i[0]; s.last_episode_learning = i[1] != 0; s.have_last = i[2] != 0; s.episode = i[3]; s.step = i[4]; s.td3_step = i[5];
+      if ((int)s.ou_x.size() != h->A) return ddrl_fail(DDRL_EIO, "%s: noise state of the wrong length", c.path.c_str());
+      std::istringstream is(std::string(eng.begin(), eng.end()));
+      is >> s.engine;
+      if (is.fail()) return ddrl_fail(DDRL_EIO, "%s: broken random engine state", c.path.c_str());
+    }
+  }
+  int dev_on = h->dev.on ? 1 : 0;
+  if ((rc = c.same("dev.on", &dev_on, sizeof(dev_on)))) return rc;
+  if (dev_on) {
+    int informed = h->dev.informed ? 1 : 0;
+    if ((rc = c.val("dev.informed", informed))) return rc;
+    if (!c.writing) h->dev.informed = informed != 0;
+    for (int g = 0; g < h->G; ++g) {
+      DevState &d = h->devst[g];
+      int i[2] = {d.last_episode_changed, (int)d.im_index};
+      if ((rc = c.vec("dev.st_w", d.st_w)) || (rc = c.vec("dev.ac_w", d.ac_w)) || (rc = c.vec("dev.all_scores", d.all_scores)) ||
+          (rc = c.host("dev.i", i, sizeof(i)))) return rc;
+      if (!c.writing) {
+        d.last_episode_changed = i[0]; d.im_index = (unsigned)i[1];
+        if (d.st_w.size() != h->dev.st_control.size() || d.ac_w.size() != h->dev.ac_control.size())
+          return ddrl_fail(DDRL_EIO, "%s: developmental gates of the wrong length", c.path.c_str());
+      }
+    }
+  }
+  const size_t G = h->G, S = h->S, A = h->A;
+  if ((rc = c.vec("last_state", h->last_state)) || (rc = c.vec("last_action", h->last_action)) || (rc = c.vec("last_pure", h->last_pure)) ||
+      (rc = c.vec("returned_ac", h->returned_ac))) return rc;
+  if (h->last_state.size() != G * S || h->last_action.size() != G * A || h->last_pure.size() != G * A || h->returned_ac.size() != G * A)
+    return ddrl_fail(DDRL_EIO, "%s: agent buffers of the wrong length", c.path.c_str());
+  if (h->algo == 2) {
+    int i[5] = {h->n_evaluated, h->generations, h->error_count, h->done_once, h->racing};
+    if ((rc = c.host("cmaesag.i", i, sizeof(i))) || (rc = c.vec("cmaesag.funvals", h->funvals)) || (rc = c.vec("cmaesag.evaluated", h->evaluated))) return rc;
+    if (!c.writing) { h->n_evaluated = i[0]; h->generations = i[1]; h->error_count = i[2]; h->done_once = i[3] != 0; h->racing = i[4] != 0; }
+    if (h->funvals.size() != G || h->evaluated.size() != G) return ddrl_fail(DDRL_EIO, "%s: fitness buffers of the wrong length", c.path.c_str());
+    if ((rc = ddrl_cmaes_checkpoint(h->es, c))) return rc;
+  }
+  return ddrl_pop_checkpoint(h->pop, c);
+}
+
+static int agents_run_file(ddrl_agents *h, const char *path, bool save) {
+  if (!h || !path) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = ddrl_pop_sync(h->pop);
+  if (rc) return rc;
+  Ckpt c;
+  if ((rc = c.open(path, save)) || (rc = agents_checkpoint(h, c))) return rc;
+  if ((rc = c.finish())) return rc;
+  if (!save && h->dev.on) return push_gates(h);          // the device gates follow the restored schedule state
+  return DDRL_OK;
+}
+extern "C" int ddrl_agents_save_run(ddrl_agents_t *h, const char *path) { return agents_run_file(h, path, true); }
+extern "C" int ddrl_agents_load_previous_run(ddrl_agents_t *h, const char *path) { return agents_run_file(h, path, false); }
 
 // ---------------------------------------------------------------------------------------------
 // G = 1 C flavour: the reference's names and argument types (ddpg.cpp:9-88; gym/agent.py:113-118)

@@ -1,0 +1,115 @@
+// ckpt.h -- the record stream behind ddrl_*_save_run / ddrl_*_load_previous_run: what
+// the reference's save_run / load_previous_run (DeepQNAg.hpp:504-537, CMAESAg.hpp:279-308; --continue,
+// Simulator.hpp:76-84,196-205) keep across a pre-emption, for a whole population in one file.
+//
+// A file is the magic "DDRLRUN1" followed by records [u32 tag length][tag][u64 payload bytes][payload].
+// ONE traversal function per object both writes and reads (Ckpt::writing picks the direction), so the two
+// cannot drift apart; on reading, every record's tag and size are checked against what the receiving
+// object expects, and a file from a different configuration is refused with DDRL_EIO before anything of
+// the object has been overwritten by it (the `meta` record comes first).  Little-endian, host layout:
+// a checkpoint is for resuming on the same kind of machine, not an exchange format.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+#include "../../include/ddrl_pop.h"
+#include "host_util.h"
+
+struct Ckpt {
+  FILE *f = nullptr;
+  bool writing = false;
+  std::string path;
+  hipStream_t st = nullptr;
+  std::vector<char> stage;
+  ~Ckpt() { if (f) fclose(f); }
+
+  int open(const char *p, bool w) {
+    if (!p) return ddrl_fail(DDRL_EINVAL, "NULL path");
+    path = p; writing = w;
+    f = fopen(p, w ? "wb" : "rb");
+    if (!f) return ddrl_fail(DDRL_EIO, "cannot open %s", p);
+    char magic[8] = {'D', 'D', 'R', 'L', 'R', 'U', 'N', '1'};
+    if (w) { if (fwrite(magic, 1, 8, f) != 8) return ddrl_fail(DDRL_EIO, "write to %s failed", p); return DDRL_OK; }
+    char got[8];
+    if (fread(got, 1, 8, f) != 8 || memcmp(got, magic, 8) != 0) return ddrl_fail(DDRL_EIO, "%s is not a ddrl_pop run file", p);
+    return DDRL_OK;
+  }
+  // record header; reading: *nbytes receives the stored size (fixed == true: it must equal the given one)
+  int head(const char *tag, uint64_t *nbytes, bool fixed) {
+    const uint32_t tl = (uint32_t)strlen(tag);
+    if (writing) {
+      if (fwrite(&tl, 4, 1, f) != 1 || fwrite(tag, 1, tl, f) != tl || fwrite(nbytes, 8, 1, f) != 1)
+        return ddrl_fail(DDRL_EIO, "write to %s failed", path.c_str());
+      return DDRL_OK;
+    }
+    uint32_t gl = 0;
+    char gt[64];
+    uint64_t gn = 0;
+    if (fread(&gl, 4, 1, f) != 1 || gl >= sizeof(gt) || fread(gt, 1, gl, f) != gl || fread(&gn, 8, 1, f) != 1)
+      return ddrl_fail(DDRL_EIO, "%s: truncated before record '%s'", path.c_str(), tag);
+    gt[gl] = 0;
+    if (gl != tl || memcmp(gt, tag, tl) != 0)
+      return ddrl_fail(DDRL_EIO, "%s does not match this object: record '%s' where '%s' was expected", path.c_str(), gt, tag);
+    if (fixed && gn != *nbytes)
+      return ddrl_fail(DDRL_EIO, "%s does not match this object: record '%s' holds %llu bytes, %llu expected", path.c_str(), tag,
+                       (unsigned long long)gn, (unsigned long long)*nbytes);
+    *nbytes = gn;
+    return DDRL_OK;
+  }
+  int payload(void *p, size_t n) {
+    if (n == 0) return DDRL_OK;
+    if (writing ? fwrite(p, 1, n, f) != n : fread(p, 1, n, f) != n)
+      return ddrl_fail(DDRL_EIO, "%s: short %s", path.c_str(), writing ? "write" : "read");
+    return DDRL_OK;
+  }
+  int host(const char *tag, void *p, size_t n) {
+    uint64_t nb = n;
+    int rc = head(tag, &nb, true);
+    return rc ? rc : payload(p, n);
+  }
+  template <class T> int val(const char *tag, T &x) { return host(tag, &x, sizeof(T)); }
+  template <class T> int vec(const char *tag, std::vector<T> &v) {          // the length travels with the record
+    uint64_t nb = v.size() * sizeof(T);
+    int rc = head(tag, &nb, false);
+    if (rc) return rc;
+    if (!writing) {
+      if (nb % sizeof(T)) return ddrl_fail(DDRL_EIO, "%s: record '%s' has a broken length", path.c_str(), tag);
+      v.resize(nb / sizeof(T));
+    }
+    return payload(v.data(), nb);
+  }
+  // device memory, through a host staging buffer on the object's stream
+  int dev(const char *tag, void *d, size_t n) {
+    uint64_t nb = n;
+    int rc = head(tag, &nb, true);
+    if (rc || n == 0) return rc;
+    if (!d) return ddrl_fail(DDRL_ESTATE, "checkpoint: no device buffer for record '%s'", tag);
+    stage.resize(n);
+    if (writing) {
+      if (hipMemcpyAsync(stage.data(), d, n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return ddrl_fail(DDRL_EHIP, "checkpoint: device read of '%s' failed", tag);
+      return payload(stage.data(), n);
+    }
+    if ((rc = payload(stage.data(), n))) return rc;
+    if (hipMemcpyAsync(d, stage.data(), n, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return ddrl_fail(DDRL_EHIP, "checkpoint: device write of '%s' failed", tag);
+    return DDRL_OK;
+  }
+  // a value that must be the same in the file and in the receiving object (shape, algorithm, sizes)
+  int same(const char *tag, const void *expect, size_t n) {
+    if (writing) return host(tag, const_cast<void *>(expect), n);
+    std::vector<char> got(n);
+    int rc = host(tag, got.data(), n);
+    if (rc) return rc;
+    if (memcmp(got.data(), expect, n) != 0)
+      return ddrl_fail(DDRL_EIO, "%s was written by a different configuration ('%s' differs)", path.c_str(), tag);
+    return DDRL_OK;
+  }
+  int finish() {
+    if (writing && (fflush(f) != 0 || ferror(f))) return ddrl_fail(DDRL_EIO, "write to %s failed", path.c_str());
+    int rc = DDRL_OK;
+    if (fclose(f) != 0 && writing) rc = ddrl_fail(DDRL_EIO, "close of %s failed", path.c_str());
+    f = nullptr;
+    return rc;
+  }
+};

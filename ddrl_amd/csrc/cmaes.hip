@@ -15,6 +15,7 @@
 #include "../../include/ddrl_pop.h"
 #include "pop_internal.h"
 #include "host_util.h"
+#include "ckpt.h"
 
 #include <dlfcn.h>
 
@@ -982,3 +983,43 @@ extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value
   }
   return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);
 }
+
+// ---- run state: what cmaes_WriteToFile(evo, "resume", ...) / cmaes_resume_distribution (cmaes.c:426-545;
+// CMAESAg.hpp:279-308) carry over, plus what they leave out and a bit-identical continuation needs: the
+// random stream, the current generation's samples, the eigensystem schedule and the termination history
+int ddrl_cmaes_checkpoint(ddrl_cmaes_t *h, Ckpt &c) {
+  c.st = h->stream;
+  int rc;
+  const int meta[3] = {h->N, h->lambda, h->mu};
+  if ((rc = c.same("cmaes.meta", meta, sizeof(meta)))) return rc;
+  const size_t N = h->N, L = h->lambda, ldn = h->ldn;
+  if ((rc = c.val("cmaes.aktseed", h->aktseed)) || (rc = c.val("cmaes.aktrand", h->aktrand)) || (rc = c.host("cmaes.rgrand", h->rgrand, sizeof(h->rgrand))) ||
+      (rc = c.val("cmaes.flgstored", h->flgstored)) || (rc = c.val("cmaes.hold", h->hold)) || (rc = c.val("cmaes.gen", h->gen)) ||
+      (rc = c.val("cmaes.countevals", h->countevals)) || (rc = c.val("cmaes.genOfEigensysUpdate", h->genOfEigensysUpdate)) ||
+      (rc = c.val("cmaes.state", h->state)) || (rc = c.val("cmaes.eigen_uptodate", h->eigen_uptodate)) ||
+      (rc = c.val("cmaes.device_rng", h->device_rng)) || (rc = c.val("cmaes.rng_seed", h->rng_seed)) || (rc = c.val("cmaes.rng_draw", h->rng_draw)) ||
+      (rc = c.val("cmaes.minEW", h->minEW)) || (rc = c.val("cmaes.maxEW", h->maxEW)) || (rc = c.val("cmaes.dMaxSignifKond", h->dMaxSignifKond)) ||
+      (rc = c.vec("cmaes.D", h->D)) || (rc = c.vec("cmaes.B", h->B)) || (rc = c.vec("cmaes.hist", h->hist)) || (rc = c.vec("cmaes.fitcur", h->fitcur)))
+    return rc;
+  if (h->D.size() != N || h->B.size() != N * N) return ddrl_fail(DDRL_EIO, "%s: eigensystem of the wrong size", c.path.c_str());
+  if ((rc = c.dev("cmaes.X", h->d_X, L * ldn * sizeof(float))) || (rc = c.dev("cmaes.DZ", h->d_DZ, L * ldn * sizeof(float))) ||
+      (rc = c.dev("cmaes.Bdev", h->d_B, N * ldn * sizeof(float))) || (rc = c.dev("cmaes.C", h->d_C, N * ldn * sizeof(float))) ||
+      (rc = c.dev("cmaes.fit", h->d_fit, L * sizeof(double))) || (rc = c.dev("cmaes.xmean", h->d_xmean, N * sizeof(double))) ||
+      (rc = c.dev("cmaes.xold", h->d_xold, N * sizeof(double))) || (rc = c.dev("cmaes.ps", h->d_ps, N * sizeof(double))) ||
+      (rc = c.dev("cmaes.pc", h->d_pc, N * sizeof(double))) || (rc = c.dev("cmaes.BDz", h->d_BDz, N * sizeof(double))) ||
+      (rc = c.dev("cmaes.Ddev", h->d_D, N * sizeof(double))) || (rc = c.dev("cmaes.sc", h->d_sc, SC_N * sizeof(double))) ||
+      (rc = c.dev("cmaes.xbest", h->d_xbest, N * sizeof(double))) || (rc = c.dev("cmaes.index", h->d_index, L * sizeof(int))))
+    return rc;
+  return DDRL_OK;
+}
+
+static int cmaes_run_file(ddrl_cmaes_t *h, const char *path, bool save) {
+  if (!h || !path) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return ddrl_fail(DDRL_EHIP, "device not available");
+  Ckpt c;
+  int rc;
+  if ((rc = c.open(path, save)) || (rc = ddrl_cmaes_checkpoint(h, c))) return rc;
+  return c.finish();
+}
+extern "C" int ddrl_cmaes_save_run(ddrl_cmaes_t *h, const char *path) { return cmaes_run_file(h, path, true); }
+extern "C" int ddrl_cmaes_load_previous_run(ddrl_cmaes_t *h, const char *path) { return cmaes_run_file(h, path, false); }

@@ -47,6 +47,10 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
 #endif
 
   STAMP(0);
+  // the diagnostics (ddrl_pop_ddpg_last) are those of the agent's LAST update of the launch: written by
+  // that workgroup only (two updates of one agent may run on different XCDs, whose L2s would write the
+  // same addresses back in no particular order)
+  const bool diag = u == P.nupd - 1;
   const int *idx = P.idx + ((size_t)agent * P.nupd + u) * B;
   // ---- n-step horizon (DeepQNAg.hpp:360-373, 394-402): the horizon stops before a transition that
   // reached the goal and at the end of the replay; rewards of steps [0, valid) are discounted ----
@@ -84,7 +88,7 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
     M.yv[trow] = M.dn[trow] != 0.f ? M.rv[trow] : (P.nstep > 0 ? M.nrew[trow] : M.rv[trow]) + gamma * qn;
   }
   __syncthreads();
-  if (P.qt_out && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];
+  if (P.qt_out && diag && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];
   STAMP(3);
 
   // ---- critic update: qnn->learn_batch(s, a, y, 1)  (DeepQNAg.hpp:408; MLP.hpp:468-485) ----
@@ -94,7 +98,7 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
     const float df = tid < B ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
     float sq = df * df;
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    if (tid == 0) P.loss_out[agent] = sq / (float)B * 0.5f;
+    if (tid == 0 && diag) P.loss_out[agent] = sq / (float)B * 0.5f;
     M.topq[tid * ldq] = df / (float)B;
   }
   __syncthreads();
@@ -133,7 +137,7 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
     // critic_backward (:429): only d/d(actions) is needed; critic parameter diffs are discarded
     float *topa = M.topa;
     const int inverting = P.inverting, out_act = na.out_act();
-    float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
+    float *dact_out = P.dact_out && diag ? P.dact_out + (size_t)agent * B * A : nullptr;
     auto store = [=](int row, int h, float diff) {
       float out = topa[row * lda + h];
       const float gt = agate ? agate[h] : 1.f;

@@ -366,3 +366,28 @@ extern "C" int ddrl_nfac_last(ddrl_pop_t *h, float *deltas, int32_t *n_pos, floa
   HIPCHK(hipStreamSynchronize(h->stream));
   return DDRL_OK;
 }
+
+// the trajectories gathered since the last update (OfflineCaclaAg keeps them in `trajectory` /
+// `trajectory_end_points`; its save_run writes none of it, a population resumed mid-batch needs them)
+int ddrl_nfac_checkpoint(ddrl_pop *h, Ckpt &c) {
+  NfacHost *n = h->nfac;
+  const size_t G = h->G, maxT = n->cfg.max_trajectory;
+  int rc;
+  const int meta[2] = {n->cfg.max_trajectory, n->rowlen};
+  if ((rc = c.same("nfac.meta", meta, sizeof(meta)))) return rc;
+  if ((rc = c.dev("nfac.traj", n->d_traj, G * maxT * n->rowlen * sizeof(float))) || (rc = c.vec("nfac.len", n->h_len))) return rc;
+  if (n->h_len.size() != G) return ddrl_fail(DDRL_EIO, "%s: trajectory bookkeeping of the wrong length", c.path.c_str());
+  std::vector<int> flat;                                 // [count, ends...] per agent
+  if (c.writing)
+    for (size_t g = 0; g < G; ++g) { flat.push_back((int)n->h_ends[g].size()); flat.insert(flat.end(), n->h_ends[g].begin(), n->h_ends[g].end()); }
+  if ((rc = c.vec("nfac.ends", flat))) return rc;
+  if (!c.writing) {
+    size_t p = 0;
+    for (size_t g = 0; g < G; ++g) {
+      if (p >= flat.size() || flat[p] < 0 || p + 1 + (size_t)flat[p] > flat.size()) return ddrl_fail(DDRL_EIO, "%s: broken trajectory end points", c.path.c_str());
+      n->h_ends[g].assign(flat.begin() + p + 1, flat.begin() + p + 1 + flat[p]);
+      p += 1 + (size_t)flat[p];
+    }
+  }
+  return DDRL_OK;
+}

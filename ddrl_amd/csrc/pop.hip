@@ -935,6 +935,83 @@ extern "C" int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *
   return DDRL_OK;
 }
 
+// ---- run state: save_run / load_previous_run (DeepQNAg.hpp:504-537) for the whole population ----
+int ddrl_pop_checkpoint(ddrl_pop *h, Ckpt &c) {
+  c.st = h->stream;
+  int rc;
+  const int B = h->algo == 0 ? h->cfg.mini_batch_size : 0, cap = h->algo == 0 ? h->cfg.replay_memory : 0;
+  const int meta[8] = {h->algo, h->G, h->cfg.nb_sensors, h->cfg.nb_motors, h->nnets, B, cap, h->rowlen};
+  if ((rc = c.same("pop.meta", meta, sizeof(meta)))) return rc;
+  const int nn = h->algo == 2 ? 1 : h->nnets;
+  for (int k = 0; k < nn; ++k) {
+    char tag[48];
+    snprintf(tag, sizeof(tag), "net%d.shape", k);
+    if ((rc = c.same(tag, &h->net[k].nd, sizeof(NetDesc)))) return rc;
+  }
+  const size_t G = h->G;
+  for (int k = 0; k < nn; ++k) {
+    TrainNet &t = h->net[k];
+    const size_t n = G * t.nd.stride() * sizeof(float);
+    char tag[48];
+    auto T = [&](const char *what) { snprintf(tag, sizeof(tag), "net%d.%s", k, what); return tag; };
+    if ((rc = c.dev(T("w"), t.st.w, n))) return rc;
+    if (t.st.wt && (rc = c.dev(T("wt"), t.st.wt, n))) return rc;
+    if (t.st.m) {
+      if ((rc = c.dev(T("m"), t.st.m, n)) || (rc = c.dev(T("v"), t.st.v, n)) || (rc = c.dev(T("iter"), t.st.iter, G * sizeof(int))) ||
+          (rc = c.dev(T("lr"), t.d_lr, G * sizeof(float))) || (rc = c.dev(T("decay"), t.d_decay, G * sizeof(float)))) return rc;
+    }
+    int ewc = t.ewc.enabled ? 1 : 0;
+    if ((rc = c.same(T("ewc"), &ewc, sizeof(ewc)))) return rc;
+    if (ewc) {
+      if ((rc = c.dev(T("fisher"), t.st.fisher, n)) || (rc = c.dev(T("fhat"), t.st.fhat, n)) || (rc = c.dev(T("wstar"), t.st.wstar, n)) ||
+          (rc = c.dev(T("best"), t.st.best, n)) || (rc = c.dev(T("fisher_nbr"), t.st.fisher_nbr, G * sizeof(float))) ||
+          (rc = c.dev(T("ewc_coef"), t.st.ewc_coef, G * sizeof(float))) ||
+          (rc = c.vec(T("best_score"), t.ewc.best_score)) || (rc = c.vec(T("decay_mult"), t.ewc.decay_mult)) ||
+          (rc = c.vec(T("last_update_best"), t.ewc.last_update_best)) || (rc = c.vec(T("best_valid"), t.ewc.best_valid)) ||
+          (rc = c.vec(T("live"), t.ewc.live))) return rc;
+      if (t.ewc.best_score.size() != G || t.ewc.decay_mult.size() != G || t.ewc.last_update_best.size() != G ||
+          t.ewc.best_valid.size() != G || t.ewc.live.size() != G) return ddrl_fail(DDRL_EIO, "%s: EWC bookkeeping of the wrong length", c.path.c_str());
+    }
+  }
+  if (h->d_tau && ((rc = c.dev("tau", h->d_tau, G * sizeof(float))) || (rc = c.dev("omtau", h->d_omtau, G * sizeof(float))))) return rc;
+  if (h->d_gamma && (rc = c.dev("gamma", h->d_gamma, G * sizeof(float)))) return rc;
+  if (h->algo == 0) {
+    // the replay rings (the reference's continue.trajectory.data) and the sampling engines
+    if ((rc = c.dev("replay", h->d_rep, G * cap * h->rowlen * sizeof(float))) || (rc = c.dev("replay.len", h->d_len, G * sizeof(int))) ||
+        (rc = c.dev("replay.head", h->d_head, G * sizeof(int))) || (rc = c.dev("mt19937", h->d_mt, G * 624 * sizeof(uint32_t))) ||
+        (rc = c.dev("mt19937.pos", h->d_mtpos, G * sizeof(int))) || (rc = c.vec("replay.h_len", h->h_len)) ||
+        (rc = c.vec("replay.h_head", h->h_head))) return rc;
+    if (h->h_len.size() != G || h->h_head.size() != G) return ddrl_fail(DDRL_EIO, "%s: replay bookkeeping of the wrong length", c.path.c_str());
+  }
+  int gates = h->gates_on ? 1 : 0;
+  if ((rc = c.val("gates.on", gates))) return rc;
+  if (gates) {
+    if (!h->d_sgate) {                                   // reading into a handle that never had gates: allocate them
+      std::vector<double> one(G * (size_t)std::max(h->cfg.nb_sensors, h->cfg.nb_motors), 1.0);
+      if ((rc = ddrl_pop_set_gates(h, one.data(), one.data()))) return rc;
+    }
+    if ((rc = c.dev("gates.state", h->d_sgate, G * h->cfg.nb_sensors * sizeof(float))) ||
+        (rc = c.dev("gates.action", h->d_agate, G * h->cfg.nb_motors * sizeof(float)))) return rc;
+  }
+  if (!c.writing) h->gates_on = gates != 0;
+  if (h->nnets == 3 && ((rc = c.dev("td3.noise_seed", h->d_nseed, G * sizeof(uint64_t))) ||
+                        (rc = c.dev("td3.noise_count", h->d_ncount, G * sizeof(uint32_t))))) return rc;
+  if (h->algo == 1 && (rc = ddrl_nfac_checkpoint(h, c))) return rc;
+  return DDRL_OK;
+}
+
+static int pop_run_file(ddrl_pop *h, const char *path, bool save) {
+  if (!h || !path) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  Ckpt c;
+  if ((rc = c.open(path, save)) || (rc = ddrl_pop_checkpoint(h, c))) return rc;
+  return c.finish();
+}
+extern "C" int ddrl_pop_save_run(ddrl_pop_t *h, const char *path) { return pop_run_file(h, path, true); }
+extern "C" int ddrl_pop_load_previous_run(ddrl_pop_t *h, const char *path) { return pop_run_file(h, path, false); }
+
 // ---- measurement hooks ----
 extern "C" int ddrl_pop_set_profiling(ddrl_pop_t *h, int on) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");

@@ -4,6 +4,7 @@
 #include "../../include/ddrl_pop.h"
 #include "pop_internal.h"
 #include "host_util.h"
+#include "ckpt.h"
 
 #include <algorithm>
 #include <cmath>
@@ -16,6 +17,12 @@
 
 struct NfacHost;   // nfac.hip
 void ddrl_nfac_host_free(NfacHost *n);
+struct ddrl_pop;
+// one traversal per object writes or reads its run state (ckpt.h); they nest: an agent front end's
+// file holds its population's records and, for CMA-ES, the optimiser's
+int ddrl_pop_checkpoint(ddrl_pop *h, Ckpt &c);          // pop.hip
+int ddrl_nfac_checkpoint(ddrl_pop *h, Ckpt &c);         // nfac.hip
+int ddrl_cmaes_checkpoint(ddrl_cmaes_t *h, Ckpt &c);    // cmaes.hip
 
 // ---------------------------------------------------------------------------------------------
 // per-net host bookkeeping of the EWC life-cycle (DODevMLP.hpp:803-822)

@@ -94,6 +94,12 @@ SYMBOLS = [
     ("ddrl_pop_ewc_decay_update", _i, [_vp, _vp]),
     ("ddrl_pop_ewc_cost", _i, [_vp, _i, _vp]),
     ("ddrl_pop_get_ewc", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_pop_save_run", _i, [_vp, _cp]),
+    ("ddrl_pop_load_previous_run", _i, [_vp, _cp]),
+    ("ddrl_cmaes_save_run", _i, [_vp, _cp]),
+    ("ddrl_cmaes_load_previous_run", _i, [_vp, _cp]),
+    ("ddrl_agents_save_run", _i, [_vp, _cp]),
+    ("ddrl_agents_load_previous_run", _i, [_vp, _cp]),
     ("ddrl_pop_set_profiling", _i, [_vp, _i]),
     ("ddrl_pop_profile_read", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     ("ddrl_pop_debug_stamps", _i, [_vp, _i, _vp]),

@@ -161,6 +161,13 @@ class Population:
         _l.check(self.L.ddrl_pop_get_ewc(self.h, net, _p(f), _p(fh), _p(ws), _p(nbr), _p(dm)))
         return dict(fisher=f, fisher_hat=fh, wstar=ws, fisher_nbr=nbr, decay_mult=dm)
 
+    # save_run / load_previous_run (DeepQNAg.hpp:504-537) for the whole population
+    def save_run(self, path):
+        _l.check(self.L.ddrl_pop_save_run(self.h, str(path).encode()))
+
+    def load_previous_run(self, path):
+        _l.check(self.L.ddrl_pop_load_previous_run(self.h, str(path).encode()))
+
     def set_profiling(self, on=True):
         _l.check(self.L.ddrl_pop_set_profiling(self.h, int(on)))
 

@@ -417,6 +417,27 @@ int ddrl_agents_create_cmaes(const char *ini_path, int nb_sensors, int nb_motors
 ddrl_cmaes_t *ddrl_agents_cmaes(ddrl_agents_t *h);            /* borrowed */
 int ddrl_agents_cmaes_state(ddrl_agents_t *h, int *lambda, int *n_evaluated, int *generations, int *error_count);
 
+/* ---- run state: save_run / load_previous_run of the reference (DeepQNAg.hpp:504-537:
+ * the four nets, the trajectory deque, the episode counter; CMAESAg.hpp:279-308: scores, counters and
+ * c-cmaes' "resume" file, cmaes.c:426-545; driven by --continue, Simulator.hpp:76-84,196-205) for a
+ * whole population in ONE file, and complete enough that the continuation is bit-identical to an
+ * uninterrupted run: weights, targets, Adam m / v / iter, per-agent hyper-parameters, EWC arrays and
+ * bookkeeping, developmental gates, the replay rings with their sampling engines (DDPG / TD3), the
+ * gathered trajectories (NFAC), the smoothing-noise streams (TD3); for CMA-ES the distribution (mean,
+ * sigma, C, B, D, ps, pc), the current generation's samples, the random stream, the eigensystem
+ * schedule and the termination history; for the agent front ends additionally every agent's episode /
+ * step counters, returns, pending action and exploration-noise engine.
+ * load_previous_run fills a handle CREATED WITH THE SAME SHAPES (algorithm, G, nets, minibatch, replay
+ * capacity; lambda and N for CMA-ES): anything else is refused with DDRL_EIO before the handle is
+ * touched.  Host byte order and layout: a file resumes on the same kind of machine. */
+int ddrl_pop_save_run(ddrl_pop_t *h, const char *path);
+int ddrl_pop_load_previous_run(ddrl_pop_t *h, const char *path);
+int ddrl_cmaes_save_run(ddrl_cmaes_t *h, const char *path);
+int ddrl_cmaes_load_previous_run(ddrl_cmaes_t *h, const char *path);
+/* the front end's file = its own state + its population's (+ the CMA-ES optimiser's) */
+int ddrl_agents_save_run(ddrl_agents_t *h, const char *path);
+int ddrl_agents_load_previous_run(ddrl_agents_t *h, const char *path);
+
 /* Measurement hooks (no counterpart in the reference, which only records total wall minutes,
  * common/include/arch/Simulator.hpp:127): with profiling on, every ddrl_pop_ddpg_update() brackets
  * its update kernel with HIP events on the handle's stream; ddrl_pop_profile_read() synchronises and
