@@ -6,10 +6,13 @@
 //   actor chunks:   pi(s), Q(s, pi(s)) with the NEW critic, dQ/da, inverting gradients, actor backward
 //   actor apply
 // One workgroup per (chunk, agent): a single agent with B = 512 still spreads over 8 CUs.
+// TD3 = true: TD3Ag's update (TD3Ag.hpp:284-380, see kernels_td3.hip) cut the same way: the critic chunk
+// smooths the target action, takes min(Q1', Q2') and produces BOTH critics' partial gradients; the actor
+// chunk and the actor's apply run for the agents on a policy step only; three applies.
 #include "ddpg_device.h"
 
 // PHASE 0: critic chunk.  PHASE 1: actor chunk.
-template <int PHASE>
+template <int PHASE, bool TD3>
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 ddpg_chunk_kernel(const DdpgParams P) {
   extern __shared__ __align__(16) float lds[];
@@ -19,6 +22,7 @@ ddpg_chunk_kernel(const DdpgParams P) {
   if (P.mask && !P.mask[agent]) return;
   const int len = P.rep_len[agent], head = P.rep_head[agent];
   if (len < 250 || len < P.B) return;                      // DeepQNAg.hpp:338
+  if (TD3 && PHASE == 1 && P.actor_step && !P.actor_step[agent]) return;   // delayed policy update (TD3Ag.hpp:333)
   const NetDesc &na = P.a, &nq = P.q;
   const int S = na.d(0), A = na.d(na.L()), B = P.B;
   const int row0 = chunk * DDRL_MB;
@@ -52,27 +56,49 @@ ddpg_chunk_kernel(const DdpgParams P) {
     gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, true, M, tid);
     __syncthreads();
     fwd_net(na, na.L(), w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);    // a' = ann_target(s')
-    actions_to_critic();
+    if (TD3) {
+      // a' = clip(a' + eps, -1, 1) (TD3Ag.hpp:307-309) between the actor's output gate and the critics' input gate
+      const float *noise = P.noise + ((size_t)agent * B + row0) * A;
+      for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+        const int row = e / A, col = e - row * A;
+        float a = M.topa[row * lda + col];
+        if (agate) a *= agate[col];
+        if (row < nrows) a = fminf(fmaxf(a + noise[row * A + col], -1.f), 1.f);
+        if (agate) a *= agate[col];
+        M.xc[row * ldxc + S + col] = a;
+      }
+      __syncthreads();
+    } else actions_to_critic();
     fwd_net(nq, nq.L(), w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);    // q' = qnn_target(s', a')
+    if (TD3) {                                                                              // Q2'(s', a') (:314)
+      if (tid < DDRL_MB) M.nrew[tid] = M.topq[tid * ldq];
+      __syncthreads();
+      fwd_net(nq, nq.L(), P.sq2.wt + (size_t)agent * nq.stride(), M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
+    }
     gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
     int trow;
     if (gather_owns_row(tid, trow)) {
-      const float qn = M.topq[trow * ldq];
-      M.yv[trow] = M.dn[trow] != 0.f ? M.rv[trow] : (P.nstep > 0 ? M.nrew[trow] : M.rv[trow]) + gamma * qn;
+      const float qn = TD3 ? fminf(M.nrew[trow], M.topq[trow * ldq]) : M.topq[trow * ldq];
+      M.yv[trow] = M.dn[trow] != 0.f ? M.rv[trow] : (!TD3 && P.nstep > 0 ? M.nrew[trow] : M.rv[trow]) + gamma * qn;
     }
     __syncthreads();
-    if (P.qt_out && tid < nrows) P.qt_out[(size_t)agent * B + row0 + tid] = M.yv[tid];
-    fwd_net(nq, nq.L(), w_q, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
-    if (tid < DDRL_MB) {
-      const float df = tid < nrows ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
-      float sq = df * df;
-      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-      if (tid == 0) P.loss_part[(size_t)agent * P.maxchunks + chunk] = sq;
-      M.topq[tid * ldq] = df / (float)B;                     // EuclideanLoss over the WHOLE minibatch
+    const float ykeep = tid < DDRL_MB ? M.yv[tid] : 0.f;
+    if (P.qt_out && tid < nrows) P.qt_out[(size_t)agent * B + row0 + tid] = ykeep;
+#pragma unroll
+    for (int k = 0; k < (TD3 ? 2 : 1); ++k) {              // qnn (and qnn2, TD3Ag.hpp:329-330) learn the same targets
+      const float *wk = k == 0 ? w_q : P.sq2.w + (size_t)agent * nq.stride();
+      fwd_net(nq, nq.L(), wk, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
+      if (tid < DDRL_MB) {
+        const float df = tid < nrows ? M.topq[tid * ldq] - ykeep : 0.f;
+        float sq = df * df;
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if (tid == 0) (k == 0 ? P.loss_part : P.loss_part2)[(size_t)agent * P.maxchunks + chunk] = sq;
+        M.topq[tid * ldq] = df / (float)B;                   // EuclideanLoss over the WHOLE minibatch
+      }
+      __syncthreads();
+      float *gout = (k == 0 ? P.gpart_q : P.gpart_q2) + ((size_t)agent * P.maxchunks + chunk) * nq.stride();
+      bwd_net<DW_STORE, false>(nq, wk, unused, gout, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid);
     }
-    __syncthreads();
-    float *gout = P.gpart_q + ((size_t)agent * P.maxchunks + chunk) * nq.stride();
-    bwd_net<DW_STORE, false>(nq, w_q, unused, gout, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid);
   } else {
     gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
     __syncthreads();
@@ -116,14 +142,18 @@ ddpg_apply_kernel(const DdpgParams P) {
   const int len = P.rep_len[agent];
   if (len < 250 || len < P.B) return;
   const NetDesc &nd = NET == 0 ? P.a : P.q;
-  const NetState &st = NET == 0 ? P.sa : P.sq;
+  const NetState &st = NET == 0 ? P.sa : NET == 1 ? P.sq : P.sq2;     // NET 2: TD3's second critic
   const int nch = (P.B + DDRL_MB - 1) / DDRL_MB;
-  const OptCtx o = make_opt<EWC>(P, st, nd.stride(), agent, P.tau[agent], P.omtau[agent], (float)P.B);
+  // TD3 (the only caller that sets actor_step): the actor waits for its policy step, and the critics' targets
+  // move on that step only (TD3Ag.hpp:333, 368-370; tau = 0 leaves w' bit-identical)
+  const bool pstep = P.actor_step ? P.actor_step[agent] != 0 : true;
+  if (NET == 0 && !pstep) return;
+  const OptCtx o = make_opt<EWC>(P, st, nd.stride(), agent, pstep ? P.tau[agent] : 0.f, pstep ? P.omtau[agent] : 1.f, (float)P.B);
   const int i = (blockIdx.x * 256 + tid) * 4;
   if (i < nd.stride()) {
     OptRegs r;
     opt_load4<EWC, true>(o, i, r);
-    const float *gp = (NET == 0 ? P.gpart_a : P.gpart_q) + (size_t)agent * P.maxchunks * nd.stride() + i;
+    const float *gp = (NET == 0 ? P.gpart_a : NET == 1 ? P.gpart_q : P.gpart_q2) + (size_t)agent * P.maxchunks * nd.stride() + i;
     f32x4 g = *(const f32x4 *)gp;
     for (int c = 1; c < nch; ++c) g += *(const f32x4 *)(gp + (size_t)c * nd.stride());
     opt_step4<EWC, true>(o, i, g, r, true);
@@ -131,31 +161,31 @@ ddpg_apply_kernel(const DdpgParams P) {
   if (blockIdx.x == 0 && tid == 0) {
     st.iter[agent] += 1;
     if (EWC) st.fisher_nbr[agent] = st.fisher_nbr[agent] * P.fisher_beta + (float)P.B;
-    if (NET == 1) {
+    if (NET >= 1) {
       float s = 0.f;
-      for (int c = 0; c < nch; ++c) s += P.loss_part[(size_t)agent * P.maxchunks + c];
-      P.loss_out[agent] = s / (float)P.B * 0.5f;
+      for (int c = 0; c < nch; ++c) s += (NET == 1 ? P.loss_part : P.loss_part2)[(size_t)agent * P.maxchunks + c];
+      (NET == 1 ? P.loss_out : P.loss2_out)[agent] = s / (float)P.B * 0.5f;
     }
   }
 }
 
 extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P);
 
-template <int PHASE>
+template <int PHASE, bool TD3 = false>
 static hipError_t launch_chunks(const DdpgParams *P, hipStream_t st) {
   static LdsConfig configured;
   const size_t lds = ddpg_update_lds_bytes(P);
-  hipError_t e = ddrl_set_lds(ddpg_chunk_kernel<PHASE>, lds, configured);
+  hipError_t e = ddrl_set_lds(ddpg_chunk_kernel<PHASE, TD3>, lds, configured);
   if (e != hipSuccess) return e;
   const int nch = (P->B + DDRL_MB - 1) / DDRL_MB;
-  hipLaunchKernelGGL(ddpg_chunk_kernel<PHASE>, dim3(nch, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  hipLaunchKernelGGL((ddpg_chunk_kernel<PHASE, TD3>), dim3(nch, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
 }
 
 template <int NET>
 static hipError_t launch_apply(const DdpgParams *P, hipStream_t st) {
   const NetDesc &nd = NET == 0 ? P->a : P->q;
-  const bool ewc = (NET == 0 ? P->sa : P->sq).fisher != nullptr;
+  const bool ewc = (NET == 0 ? P->sa : NET == 1 ? P->sq : P->sq2).fisher != nullptr;
   const dim3 grid((nd.stride_ + 1023) / 1024, P->G);
   if (ewc) hipLaunchKernelGGL((ddpg_apply_kernel<NET, true>), grid, dim3(256), 0, st, *P);
   else hipLaunchKernelGGL((ddpg_apply_kernel<NET, false>), grid, dim3(256), 0, st, *P);
@@ -163,7 +193,7 @@ static hipError_t launch_apply(const DdpgParams *P, hipStream_t st) {
 }
 
 extern "C" hipError_t ddpg_apply_launch(const DdpgParams *P, int net, hipStream_t st) {
-  return net == 0 ? launch_apply<0>(P, st) : launch_apply<1>(P, st);
+  return net == 0 ? launch_apply<0>(P, st) : net == 1 ? launch_apply<1>(P, st) : launch_apply<2>(P, st);
 }
 
 extern "C" hipError_t ddpg_update_big_launch(const DdpgParams *P, hipStream_t st) {
@@ -171,5 +201,17 @@ extern "C" hipError_t ddpg_update_big_launch(const DdpgParams *P, hipStream_t st
   if ((e = launch_chunks<0>(P, st)) != hipSuccess) return e;
   if ((e = launch_apply<1>(P, st)) != hipSuccess) return e;
   if ((e = launch_chunks<1>(P, st)) != hipSuccess) return e;
+  return launch_apply<0>(P, st);
+}
+
+// TD3Ag's update for minibatches of more than 64 rows (or forced): critic chunks for both critics, their
+// applies, then -- `any_actor`: some agent is on a policy step -- the actor chunks and the actor's apply
+extern "C" hipError_t td3_update_big_launch(const DdpgParams *P, int any_actor, hipStream_t st) {
+  hipError_t e;
+  if ((e = launch_chunks<0, true>(P, st)) != hipSuccess) return e;
+  if ((e = launch_apply<1>(P, st)) != hipSuccess) return e;
+  if ((e = launch_apply<2>(P, st)) != hipSuccess) return e;
+  if (!any_actor) return hipSuccess;
+  if ((e = launch_chunks<1, true>(P, st)) != hipSuccess) return e;
   return launch_apply<0>(P, st);
 }

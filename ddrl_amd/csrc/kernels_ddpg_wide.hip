@@ -42,14 +42,16 @@ __device__ __forceinline__ WideMap wide_map(const DdpgParams &P, int agent, int 
   return W;
 }
 
-// the update guard of DeepQNAg.hpp:338 + mask + chunks beyond the minibatch
-__device__ __forceinline__ bool wide_skip(const DdpgParams &P, int agent, int chunk) {
+// the update guard of DeepQNAg.hpp:338 + mask + chunks beyond the minibatch; policy: a launch of TD3's
+// delayed actor update, only for the agents on a policy step (TD3Ag.hpp:333)
+__device__ __forceinline__ bool wide_skip(const DdpgParams &P, int agent, int chunk, int policy = 0) {
   if (P.mask && !P.mask[agent]) return true;
+  if (policy && P.actor_step && !P.actor_step[agent]) return true;
   const int len = P.rep_len[agent];
   return len < 250 || len < P.B || chunk * DDRL_MB >= P.B;
 }
 
-struct WideOp { int net, target, l, mode; };
+struct WideOp { int net, target, l, mode, policy; };      // net: 0 actor, 1 critic, 2 second critic (TD3)
 
 // where layer l of a net reads its input / writes its output inside the scratch block
 __device__ __forceinline__ void wide_io(const DdpgParams &P, const WideMap &W, int net, int l, const NetDesc &nd,
@@ -66,10 +68,10 @@ __device__ __forceinline__ void wide_io(const DdpgParams &P, const WideMap &W, i
 __global__ void __launch_bounds__(256)
 wide_fwd_kernel(const DdpgParams P, const WideOp op) {
   const int nb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
-  if (wide_skip(P, agent, chunk)) return;
+  if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const NetDesc &nd = op.net ? P.q : P.a;
-  const NetState &st = op.net ? P.sq : P.sa;
+  const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
   const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
   const float *wn = (op.target ? st.wt : st.w) + (size_t)agent * nd.stride();
   const float *Wl = wn + nd.offw(l), *bias = wn + nd.offb(l);
@@ -129,10 +131,10 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
 __global__ void __launch_bounds__(256)
 wide_dx_kernel(const DdpgParams P, const WideOp op) {
   const int kb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
-  if (wide_skip(P, agent, chunk)) return;
+  if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const NetDesc &nd = op.net ? P.q : P.a;
-  const NetState &st = op.net ? P.sq : P.sa;
+  const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
   const int l = op.l, kp = nd.kp(l), K = nd.d(l), N = nd.d(l + 1);
   const float *Wl = st.w + (size_t)agent * nd.stride() + nd.offw(l);
   const WideMap W = wide_map(P, agent, chunk);
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(256)
 wide_dw_kernel(const DdpgParams P, const WideOp op) {
   __shared__ __align__(16) float sY[DDRL_MB * 68], sX[DDRL_MB * 68];
   const int chunk = blockIdx.y, agent = blockIdx.z;
-  if (wide_skip(P, agent, chunk)) return;
+  if (wide_skip(P, agent, chunk, op.policy)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
   const NetDesc &nd = op.net ? P.q : P.a;
   const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
@@ -211,7 +213,7 @@ wide_dw_kernel(const DdpgParams P, const WideOp op) {
   }
   __syncthreads();
   const int Nloc = N - nb * 64 < 64 ? N - nb * 64 : 64, kploc = kp - kb * 64 < 64 ? kp - kb * 64 : 64;
-  float *gout = (op.net ? P.gpart_q : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
+  float *gout = (op.net == 2 ? P.gpart_q2 : op.net ? P.gpart_q : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
 #pragma unroll 1
   for (int t = 0; t < 4; ++t) {
     const int p = wave * 4 + t;
@@ -224,9 +226,9 @@ wide_dw_kernel(const DdpgParams P, const WideOp op) {
 
 // the element-wise steps between the layer launches, one workgroup per (chunk, agent)
 __global__ void __launch_bounds__(DDRL_NTHREADS)
-wide_step_kernel(const DdpgParams P, int step) {
+wide_step_kernel(const DdpgParams P, int step, int policy) {
   const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x;
-  if (wide_skip(P, agent, chunk)) return;
+  if (wide_skip(P, agent, chunk, policy)) return;
   const WideMap W = wide_map(P, agent, chunk);
   const LdsMap &M = W.M;
   const int S = P.S, A = P.A, B = P.B;
@@ -270,6 +272,35 @@ wide_step_kernel(const DdpgParams P, int step) {
     }
   } else if (step == 4) {                // DPG seed (:424-428), NOT / B
     if (tid < DDRL_MB) M.topq[tid * ldq] = tid < nrows ? -1.0f : 0.f;
+  } else if (step == 6) {                // TD3: a' = clip(a' + eps, -1, 1) between the two gates (TD3Ag.hpp:307-309)
+    const float *noise = P.noise + ((size_t)agent * B + row0) * A;
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+      const int row = e / A, col = e - row * A;
+      float a = M.topa[row * lda + col];
+      if (agate) a *= agate[col];
+      if (row < nrows) a = fminf(fmaxf(a + noise[row * A + col], -1.f), 1.f);
+      if (agate) a *= agate[col];
+      M.xc[row * ldxc + S + col] = a;
+    }
+  } else if (step == 7) {                // TD3: Q1'(s', a') aside while the second target critic runs (:313-314)
+    if (tid < DDRL_MB) M.nrew[tid] = M.topq[tid * ldq];
+  } else if (step == 8) {                // TD3: [s|a] tiles + y = r + gamma min(Q1', Q2') (:317-326)
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
+    int trow;
+    if (gather_owns_row(tid, trow)) {
+      const float qn = fminf(M.nrew[trow], M.topq[trow * ldq]);
+      const float y = M.dn[trow] != 0.f ? M.rv[trow] : M.rv[trow] + gamma * qn;
+      M.yv[trow] = y;
+      if (P.qt_out && trow < nrows) P.qt_out[(size_t)agent * B + row0 + trow] = y;
+    }
+  } else if (step == 9) {                // TD3: the second critic's EuclideanLoss
+    if (tid < DDRL_MB) {
+      const float df = tid < nrows ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
+      float sq = df * df;
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+      if (tid == 0) P.loss_part2[(size_t)agent * P.maxchunks + chunk] = sq;
+      M.topq[tid * ldq] = df / (float)B;
+    }
   } else {                               // inverting gradients (:432-450) and the actor's output layer
     const int ldda = ddrl_ldpad(A), out_act = P.a.out_act();
     float *dact_out = P.dact_out ? P.dact_out + ((size_t)agent * B + row0) * A : nullptr;
@@ -295,28 +326,51 @@ extern "C" hipError_t ddpg_apply_launch(const DdpgParams *P, int net, hipStream_
 
 #define WIDE_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-extern "C" hipError_t ddpg_update_wide_launch(const DdpgParams *Pp, hipStream_t st) {
+// td3 == 0: DeepQNAg's update.  td3 != 0: TD3Ag's (TD3Ag.hpp:284-380) -- smoothed target action, two target
+// critics, both critics' learn_batch, and (any_actor: some agent is on a policy step) the actor phase
+// launched for those agents only.
+static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipStream_t st) {
   const DdpgParams &P = *Pp;
   const int C = (P.B + DDRL_MB - 1) / DDRL_MB, G = P.G;
-  auto step = [&](int s) { hipLaunchKernelGGL(wide_step_kernel, dim3(C, G), dim3(DDRL_NTHREADS), 0, st, P, s); };
+  int policy = 0;                                           // set for the launches of TD3's actor phase
+  auto step = [&](int s) { hipLaunchKernelGGL(wide_step_kernel, dim3(C, G), dim3(DDRL_NTHREADS), 0, st, P, s, policy); };
   auto fwd = [&](int net, int target) {
     const NetDesc &nd = net ? P.q : P.a;
     for (int l = 0; l < nd.L_; ++l) {
-      const WideOp op = {net, target, l, 0};
+      const WideOp op = {net, target, l, 0, policy};
       hipLaunchKernelGGL(wide_fwd_kernel, dim3((nd.ld_[l + 1] + 63) / 64, C, G), dim3(256), 0, st, P, op);
     }
   };
   auto dx = [&](int net, int l, int mode) {
     const NetDesc &nd = net ? P.q : P.a;
-    const WideOp op = {net, 0, l, mode};
+    const WideOp op = {net, 0, l, mode, policy};
     hipLaunchKernelGGL(wide_dx_kernel, dim3((nd.kp_[l] + 63) / 64, C, G), dim3(256), 0, st, P, op);
   };
   auto dw = [&](int net, int l) {
     const NetDesc &nd = net ? P.q : P.a;
-    const WideOp op = {net, 0, l, 0};
+    const WideOp op = {net, 0, l, 0, policy};
     hipLaunchKernelGGL(wide_dw_kernel, dim3(((nd.d_[l + 1] + 63) / 64) * ((nd.kp_[l] + 63) / 64), C, G), dim3(256), 0, st, P, op);
   };
   hipError_t e;
+  if (td3) {
+    // y = r + gamma min(Q1', Q2')(s', clip(pi'(s') + eps)), then both critics learn it (:304-330)
+    step(0); fwd(0, 1); step(6); fwd(1, 1); step(7); fwd(2, 1); step(8);
+    for (int k = 1; k <= 2; ++k) {
+      fwd(k, 0); step(k == 1 ? 3 : 9);
+      for (int l = P.q.L_ - 1; l >= 0; --l) { dw(k, l); if (l > 0) dx(k, l, 0); }
+      WIDE_CHECK();
+      if ((e = ddpg_apply_launch(Pp, k, st)) != hipSuccess) return e;
+    }
+    if (!any_actor) return hipSuccess;
+    policy = 1;                                             // the delayed actor update through the first critic (:333-363)
+    fwd(0, 0); step(1); fwd(1, 0); step(4);
+    for (int l = P.q.L_ - 1; l >= 1; --l) dx(1, l, 0);
+    dx(1, 0, 1);
+    step(5);
+    for (int l = P.a.L_ - 1; l >= 0; --l) { dw(0, l); if (l > 0) dx(0, l, 0); }
+    WIDE_CHECK();
+    return ddpg_apply_launch(Pp, 0, st);
+  }
   // critic: y = r + gamma Q'(s', pi'(s')), then learn_batch (DeepQNAg.hpp:379-408)
   step(0); fwd(0, 1); step(1); fwd(1, 1); step(2); fwd(1, 0); step(3);
   for (int l = P.q.L_ - 1; l >= 0; --l) { dw(1, l); if (l > 0) dx(1, l, 0); }
@@ -331,3 +385,6 @@ extern "C" hipError_t ddpg_update_wide_launch(const DdpgParams *Pp, hipStream_t 
   WIDE_CHECK();
   return ddpg_apply_launch(Pp, 0, st);
 }
+
+extern "C" hipError_t ddpg_update_wide_launch(const DdpgParams *P, hipStream_t st) { return wide_launch(P, 0, 0, st); }
+extern "C" hipError_t td3_update_wide_launch(const DdpgParams *P, int any_actor, hipStream_t st) { return wide_launch(P, 1, any_actor, st); }

@@ -14,6 +14,8 @@ hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G,
                               const float *lr_q, const int *iter_a, const int *iter_q, float *lrt_a, float *lrt_q,
                               int *upd_done, hipStream_t st);
 hipError_t td3_update_launch(const DdpgParams *P, int force_generic, hipStream_t st);
+hipError_t td3_update_big_launch(const DdpgParams *P, int any_actor, hipStream_t st);
+hipError_t td3_update_wide_launch(const DdpgParams *P, int any_actor, hipStream_t st);
 hipError_t td3_prep_launch(const uint64_t *seed, uint32_t *count, const int *rep_len, int G, int B, int A,
                            const uint8_t *mask, float *noise, int draw, float sigma, float clip, double beta1,
                            double beta2, const float *lr_q2, const int *iter_q2, float *lrt_q2, hipStream_t st);
@@ -128,11 +130,6 @@ static int validate(const ddrl_ddpg_config *c) {
   if (c->td3) {
     if (c->policy_freq < 1) return ddrl_fail(DDRL_EINVAL, "policy_freq < 1");
     if (!(c->policy_noise >= 0.) || !(c->noise_clip >= 0.)) return ddrl_fail(DDRL_EINVAL, "policy_noise / noise_clip < 0");
-    if (c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "TD3: mini_batch_size > %d is not supported in this round", DDRL_MB);
-    bool wide = c->nb_sensors + c->nb_motors > DDRL_MAXW;
-    for (int i = 0; i < c->n_hidden_a; ++i) wide = wide || c->hidden_unit_a[i] > DDRL_MAXW;
-    for (int i = 0; i < c->n_hidden_q; ++i) wide = wide || c->hidden_unit_q[i] > DDRL_MAXW;
-    if (wide) return ddrl_fail(DDRL_EINVAL, "TD3: layers wider than %d are not supported in this round", DDRL_MAXW);
     if (c->nstep_return > 0 || c->inverting_grad || c->force_more_update)
       return ddrl_fail(DDRL_EINVAL, "TD3Ag has no nstep_return / inverting_grad / force_more_update");
   }
@@ -149,6 +146,10 @@ static int chunk_buffers(ddrl_pop *h) {
     if ((rc = dalloc(h, &P.gpart_a, G * C * h->net[0].nd.stride()))) return rc;
     if ((rc = dalloc(h, &P.gpart_q, G * C * h->net[1].nd.stride()))) return rc;
     if ((rc = dalloc(h, &P.loss_part, G * C))) return rc;
+    if (h->nnets == 3) {
+      if ((rc = dalloc(h, &P.gpart_q2, G * C * h->net[2].nd.stride()))) return rc;
+      if ((rc = dalloc(h, &P.loss_part2, G * C))) return rc;
+    }
   }
   if (h->wide && !P.wide) {
     P.wide_stride = ddpg_wide_block_floats(&P);
@@ -715,7 +716,15 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
     h->ev_used++;
     HIPCHK(hipEventRecord(e0, h->stream));
   }
-  HIPCHK(td3_update_launch(&P, h->force_generic, h->stream));
+  int any_actor = actor_step ? 0 : 1;
+  for (int g = 0; g < G && !any_actor; ++g) any_actor = actor_step[g] && (!mask || mask[g]);
+  if (h->wide) {
+    HIPCHK(td3_update_wide_launch(&P, any_actor, h->stream));
+  } else if (P.maxchunks > 1 || h->force_chunked) {
+    HIPCHK(td3_update_big_launch(&P, any_actor, h->stream));
+  } else {
+    HIPCHK(td3_update_launch(&P, h->force_generic, h->stream));
+  }
   if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   if (idx || mask || noise || actor_step) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;

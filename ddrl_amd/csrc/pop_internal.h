@@ -142,6 +142,8 @@ struct DdpgParams {
   const float *noise;       // [G x B x A]
   const uint8_t *actor_step;   // [G] or null (= every agent's actor is updated)
   float *loss2_out;         // [G]
+  float *gpart_q2;          // [G x maxchunks x stride]: the second critic's per-chunk partial gradients (minibatches > 64 rows)
+  float *loss_part2;        // [G x maxchunks]
   int nupd;                 // consecutive updates per launch (>= 1): idx is [G x nupd x B], lr_t [G x nupd]
   int *upd_done;            // [G] updates of this launch an agent has completed (zeroed by the prep kernel)
   int *upd_error;           // [1] raised when a workgroup gave up waiting for its predecessor

@@ -151,8 +151,9 @@ int ddrl_pop_ddpg_update_n(ddrl_pop_t *h, int n, const int32_t *idx, const uint8
  * ddrl_td3_config_from_ini reads the keys TD3Ag's _unique_invoke reads (TD3Ag.hpp:165-186: DeepQNAg's
  * without inverting_grad / force_more_update / nstep_return, plus policy_noise, noise_clip,
  * policy_freq) and sets td3 = 1; ddrl_td3_create = ddrl_ddpg_create on such a config: six nets per
- * agent (ann, qnn, qnn2 and their targets, TD3Ag.hpp:208-230).  This round: one-tile minibatches
- * (mini_batch_size <= 64) and layers up to 128 wide.  Every other ddrl_pop_* entry point applies
+ * agent (ann, qnn, qnn2 and their targets, TD3Ag.hpp:208-230).  Same limits as DDPG (mini_batch_size
+ * <= 4096, layers <= 1024 wide): one fused launch for one-tile minibatches of nets up to 128 wide, the
+ * chunk + apply kernels above 64 rows, the layer-by-layer kernels for wider nets.  Every other ddrl_pop_* entry point applies
  * (alpha_v / decay_v set both critics; the EWC calls cover qnn2 like qnn). */
 int ddrl_td3_config_from_ini(const char *path, ddrl_ddpg_config *cfg);
 int ddrl_td3_create(const ddrl_ddpg_config *cfg, uint64_t init_seed, ddrl_pop_t **out);

@@ -134,6 +134,38 @@ def test_td3_update_matches_oracle(ora, hidden_a, hidden_q, generic):
     step_and_check(pop, agents, idx[:, ::-1].copy(), 4 * noise, [0, 1, 1, 0])
 
 
+@pytest.mark.parametrize("B,forced", [(160, False), (512, False), (48, True)])
+def test_td3_large_minibatch(ora, B, forced):
+    """minibatches above 64 rows (the reference's inis use 512): critic chunks for both critics, three applies,
+    actor chunks for the agents on a policy step; `forced` runs the same kernels on a one-tile minibatch"""
+    G = 3
+    pop, agents = make_td3(ora, G=G, B=B, hidden_a=(64, 32), hidden_q=(48, 40), seed=6)
+    if forced:
+        pop.set_option("force_chunked", 1)
+    rng = np.random.RandomState(3)
+    for it, astep in enumerate(([1, 0, 1], [0, 0, 0], None)):
+        idx = rng.randint(0, 1000, (G, B)).astype(np.int32) if it < 2 else None
+        noise = np.clip(rng.normal(0, 0.3, (G, B, 6)), -0.5, 0.5).astype(np.float32) if it < 2 else None
+        step_and_check(pop, agents, idx, noise, astep)
+
+
+@pytest.mark.parametrize("B,hidden_a,hidden_q,forced", [
+    (64, (160, 96), (144, 130), False),          # wider than the LDS-resident kernels: layer-by-layer launches
+    (100, (400, 300), (400, 300), False),        # the TD3 paper's nets (BASELINE.md "large"), two chunks
+    (48, (24, 16), (20, 12), True),              # the same launches forced on small nets
+])
+def test_td3_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, forced):
+    G = 2
+    pop, agents = make_td3(ora, G=G, B=B, hidden_a=hidden_a, hidden_q=hidden_q, seed=8, wscale=0.05)
+    if forced:
+        pop.set_option("force_wide", 1)
+    rng = np.random.RandomState(4)
+    for it, astep in enumerate(([1, 0], [0, 0], None)):
+        idx = rng.randint(0, 1000, (G, B)).astype(np.int32) if it < 2 else None
+        noise = np.clip(rng.normal(0, 0.3, (G, B, 6)), -0.5, 0.5).astype(np.float32) if it < 2 else None
+        step_and_check(pop, agents, idx, noise, astep)
+
+
 def test_td3_free_indices_and_device_noise(ora):
     """device-drawn indices (bit-exact with the oracle's mt19937) and device-drawn smoothing noise,
     six updates with the policy step every second one"""
@@ -233,7 +265,7 @@ def test_td3_entry_point_guards():
     w = td3.weights(1)
     td3.update()
     assert np.array_equal(td3.weights(1), w) and np.all(td3.adam(4)[2] == 0)
-    for bad in (dict(mini_batch_size=128), dict(hidden_unit_q=(400, 300)), dict(nstep_return=3), dict(policy_freq=0)):
+    for bad in (dict(hidden_unit_q=(2000, 300)), dict(nstep_return=3), dict(policy_freq=0)):
         c = ddrl_amd.DdpgConfig(n_agents=2, replay_memory=300, inverting_grad=0, td3=1, **bad)
         with pytest.raises(ddrl_amd.DdrlError):
             ddrl_amd.Td3Population(c)
