@@ -7,4 +7,5 @@ it has no CPU path and raises if the library is missing.
 from .lib import load, LibraryMissing, DdrlError  # noqa: F401
 from .population import DdpgConfig, DdpgPopulation, Td3Population, NfacConfig, NfacPopulation, PolicyPopulation  # noqa: F401
 from .cmaes import Cmaes  # noqa: F401
+from .sim import Simulator  # noqa: F401
 from .agents import DdpgAgents, Td3Agents, NfacAgents, CmaesAgents, DDRLAg  # noqa: F401

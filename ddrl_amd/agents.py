@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _l
-from .population import NfacPopulation, PolicyPopulation, Population, Td3Population, _p
+from .population import DdpgPopulation, NfacPopulation, PolicyPopulation, Population, Td3Population, _p
 
 
 class _Borrowed(Population):
@@ -67,9 +67,13 @@ class _Agents:
         return dict(sum_weighted_reward=swr, sum_reward=sr, episode=ep)
 
 
+class _BorrowedDdpg(_Borrowed, DdpgPopulation):
+    pass
+
+
 class DdpgAgents(_Agents):
     """G DDPG agents driven step by step: ARLAgent::runf + DeepQNAg::_run for every agent per call."""
-    _view = _Borrowed
+    _view = _BorrowedDdpg
 
     def __init__(self, ini_path, n_agents, nb_sensors, nb_motors, seed=0, device=-1):
         self.L = _l.load()

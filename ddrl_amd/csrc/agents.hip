@@ -487,6 +487,14 @@ extern "C" int ddrl_agents_create_cmaes(const char *ini_path, int nb_sensors, in
 }
 
 extern "C" ddrl_pop_t *ddrl_agents_population(ddrl_agents_t *h) { return h ? h->pop : nullptr; }
+extern "C" int ddrl_agents_shape(ddrl_agents_t *h, int *kind, int *n_agents, int *nb_sensors, int *nb_motors) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  if (kind) *kind = h->algo;
+  if (n_agents) *n_agents = h->G;
+  if (nb_sensors) *nb_sensors = h->S;
+  if (nb_motors) *nb_motors = h->A;
+  return DDRL_OK;
+}
 extern "C" ddrl_cmaes_t *ddrl_agents_cmaes(ddrl_agents_t *h) { return h ? h->es : nullptr; }
 
 extern "C" int ddrl_agents_cmaes_state(ddrl_agents_t *h, int *lambda, int *n_evaluated, int *generations, int *error_count) {

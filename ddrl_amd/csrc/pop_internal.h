@@ -6,8 +6,8 @@
 #define DDRL_MAXL 4          // InnerProduct layers per net = hidden (<=3) + output
 #define DDRL_MB 64           // rows per workgroup batch tile (4 MFMA m-tiles of 16)
 #ifndef DDRL_NWAVES
-#define DDRL_NWAVES 8        // 512-thread workgroups: two waves per SIMD; 2 workgroups per CU => 4 waves per SIMD
-#endif
+#define DDRL_NWAVES 4        // 256-thread workgroups, one wave per SIMD: each wave carries 16 of the 64 batch rows (mlp_device.h);
+#endif                       // two workgroups per CU (LDS, and 256 VGPRs per wave) => two waves per SIMD
 #define DDRL_NTHREADS (DDRL_NWAVES * 64)
 #define DDRL_MAXUPD 64       // consecutive updates one launch may run (ddrl_pop_ddpg_update_n)
 #define DDRL_MAXB 4096       // largest minibatch (chunks of DDRL_MB rows, kernels_ddpg_big.hip)

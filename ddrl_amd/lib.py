@@ -53,6 +53,19 @@ class NfacConfigC(C.Structure):
     ]
 
 
+class EnvVtable(C.Structure):
+    """ddrl_env_vtable: the reference's Environment interface as C callbacks (one instance per agent)"""
+    RESET = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
+    PERCEPTIONS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double))
+    PERFORMANCE = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int)
+    APPLY = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double))
+    FLAG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+    NEXT = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
+    DUMP = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p, C.c_int)      # (a c_char_p argument would arrive as a copy)
+    _fields_ = [("user", C.c_void_p), ("reset_episode", RESET), ("perceptions", PERCEPTIONS), ("performance", PERFORMANCE),
+                ("apply", APPLY), ("running", FLAG), ("final_state", FLAG), ("next_instance", NEXT), ("dump", DUMP)]
+
+
 # every symbol include/ddrl_pop.h declares: (name, restype, argtypes)
 _vp, _i, _cp = C.c_void_p, C.c_int, C.c_char_p
 SYMBOLS = [
@@ -100,6 +113,11 @@ SYMBOLS = [
     ("ddrl_cmaes_load_previous_run", _i, [_vp, _cp]),
     ("ddrl_agents_save_run", _i, [_vp, _cp]),
     ("ddrl_agents_load_previous_run", _i, [_vp, _cp]),
+    ("ddrl_agents_shape", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("ddrl_sim_create", _i, [_vp, C.POINTER(EnvVtable), _cp, _cp, _i, _i, C.POINTER(_vp)]),
+    ("ddrl_sim_destroy", _i, [_vp]),
+    ("ddrl_sim_run", _i, [_vp]),
+    ("ddrl_sim_run_episode", _i, [_vp, _i, C.c_long, C.c_long]),
     ("ddrl_pop_set_profiling", _i, [_vp, _i]),
     ("ddrl_pop_profile_read", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
     ("ddrl_pop_debug_stamps", _i, [_vp, _i, _vp]),

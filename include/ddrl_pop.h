@@ -439,6 +439,44 @@ int ddrl_cmaes_load_previous_run(ddrl_cmaes_t *h, const char *path);
 int ddrl_agents_save_run(ddrl_agents_t *h, const char *path);
 int ddrl_agents_load_previous_run(ddrl_agents_t *h, const char *path);
 
+/* what a front end drives: kind 0 DDPG, 1 NFAC, 2 CMA-ES, 3 TD3; any pointer may be NULL */
+int ddrl_agents_shape(ddrl_agents_t *h, int *kind, int *n_agents, int *nb_sensors, int *nb_motors);
+
+/* ---- batched environment front end: arch::Simulator (Simulator.hpp:76-248) for a
+ * population.  One environment instance per agent, supplied as a table of C callbacks (the reference's
+ * Environment interface: reset_episode, perceptions, performance, apply, running, final_state,
+ * next_instance; common/include/arch/AEnvironment.hpp), stepped by a pool of n_threads host threads in
+ * lock step; every tick is ONE ddrl_agents_run over [G x ...] batches.  Environments may finish at
+ * different steps.  `env` is the environment / agent index; a given env is called from one thread at
+ * a time, different envs concurrently.  dump (optional) writes the environment's log fields. */
+typedef struct {
+  void *user;
+  void (*reset_episode)(void *user, int env, int learning);
+  void (*perceptions)(void *user, int env, double *out /* [nb_sensors] */);
+  double (*performance)(void *user, int env);
+  void (*apply)(void *user, int env, const double *actuators /* [nb_motors] */);
+  int (*running)(void *user, int env);
+  int (*final_state)(void *user, int env);
+  void (*next_instance)(void *user, int env, int learning);          /* may be NULL */
+  void (*dump)(void *user, int env, char *buf, int buf_len);         /* may be NULL */
+} ddrl_env_vtable;
+typedef struct ddrl_sim ddrl_sim_t;
+/* reads the [simulation] keys of the ini (max_episode, test_episode_per_episode, test_episode_at_end,
+ * dump_log_each, display_log_each, save_agent_each; optional display_learning, continue_save_each;
+ * Simulator.hpp:300-328).  Log lines go to <out_dir>/<agent>/0.learning.data and
+ * <out_dir>/<agent>/0.<test episode>.testing.data in the reference's format (:236-245: episode, steps,
+ * the agent's dump fields, the environment's), elapsed minutes to <out_dir>/time_elapsed (:127).
+ * can_continue != 0 is --continue (:76-84, 196-205): every continue_save_each learning episodes the
+ * run state goes to <out_dir>/continue.ddrl_pop (ddrl_agents_save_run) + continue.simu.data, and a
+ * create that finds them resumes from there.  The agents handle is borrowed. */
+int ddrl_sim_create(ddrl_agents_t *agents, const ddrl_env_vtable *env, const char *ini_path, const char *out_dir,
+                    int n_threads, int can_continue, ddrl_sim_t **out);
+int ddrl_sim_destroy(ddrl_sim_t *s);
+/* Simulator::run (:86-128): the learning / testing episode schedule */
+int ddrl_sim_run(ddrl_sim_t *s);
+/* Simulator::run_episode (:139-208) for all G (agent, environment) pairs */
+int ddrl_sim_run_episode(ddrl_sim_t *s, int learning, long lepisode, long tepisode);
+
 /* Measurement hooks (no counterpart in the reference, which only records total wall minutes,
  * common/include/arch/Simulator.hpp:127): with profiling on, every ddrl_pop_ddpg_update() brackets
  * its update kernel with HIP events on the handle's stream; ddrl_pop_profile_read() synchronises and
