@@ -97,7 +97,8 @@ __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__rest
 // dx0_store(row, col - c0, value); the caller synchronises before other waves read what it wrote.
 enum { DW_NONE = 0, DW_OPT = 1, DW_STORE = 2 };
 #define DDRL_PARK_TILES 4     // input-gradient tiles (of up to DDRL_MAXKC) parked in LDS during a deep layer's optimiser loop
-template <int TRAIN, bool EWC, class ND, class DX0>
+// TGT: the optimiser epilogue also moves the net's target twin (false: TD3's critics between two policy steps)
+template <int TRAIN, bool EWC, bool TGT = true, class ND, class DX0>
 __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w, const OptCtx opt, float *gout,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                         int c0, int nc, DX0 dx0_store, int wave, int lane, int tid,
@@ -131,8 +132,8 @@ __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w
           for (int i = 0; i < DDRL_PARK_TILES; ++i)
             if (kt0 + i < kt1) *(f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4) = acc[i];
         }
-        if (deep) bwd_dw_opt<EWC, true, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
-        else bwd_dw_opt<EWC, true, false>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+        if (deep) bwd_dw_opt<EWC, TGT, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+        else bwd_dw_opt<EWC, TGT, false>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
         if (deep && need_dx) {
 #pragma unroll
           for (int i = 0; i < DDRL_PARK_TILES; ++i)
