@@ -191,7 +191,11 @@ __device__ __forceinline__ void ddpg_update_once(const DdpgParams &P, float *lds
 // spreads the optimiser's HBM streaming over time (section 4.1 of DESIGN.md), and the tail of one pass
 // overlaps the head of the next.
 template <class NA, class NQ, bool EWC_A, bool EWC_Q>
+#ifdef DDRL_EXP_SPILL    // measurement / robustness build: a register budget the kernel does not fit (forces scratch spills)
+__global__ void __launch_bounds__(DDRL_NTHREADS, 3)
+#else
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU
+#endif
 ddpg_update_kernel(const DdpgParams P) {
   extern __shared__ __align__(16) float lds[];
   const int u = P.nupd > 1 ? (int)blockIdx.x / P.G : 0;
