@@ -196,7 +196,14 @@ def main():
     tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("bytes_per_launch_%d_%s_upl%d" % (G, args.size, int(round(upl_eff))))
+            # measured HBM bytes per launch (PMC, profiles/README.md) for 1 and for 8 updates per launch; a launch with
+            # another count (--steps not a multiple of 8 leaves a shorter last launch) is priced per update from the nearer one
+            tj = json.load(open(tp))
+            per_update = {n: tj.get("bytes_per_launch_%d_%s_upl%d" % (G, args.size, n)) for n in (1, 8)}
+            per_update = {n: v / n for n, v in per_update.items() if v}
+            if per_update:
+                near = min(per_update, key=lambda n: abs(n - upl_eff))
+                traffic = per_update[near] * upl_eff
         except Exception:
             traffic = None
     out = {

@@ -380,3 +380,42 @@ def test_fused_consecutive_updates(ora, B, hidden, kw):
         w, wo = popa.weights(net), oracle_weights(agents, net)
         for g in range(G):
             assert close_frac(w[g], wo[g], 1e-4, 0.99, 1e-2), (net, g)
+
+
+def test_fused_consecutive_updates_full_chip():
+    """the same identity at the bench's scale: 8 x 1100 workgroups against 512 resident slots, so an agent's
+    consecutive updates run in different dispatch rounds, on different CUs and XCDs (the sc1 hand-off), EWC live;
+    and the diagnostics are those of the LAST update"""
+    import ddrl_amd
+    from bench import synth_rows
+    G, n = 1100, 8
+    pops = []
+    for _ in range(2):
+        cfg = ddrl_amd.DdpgConfig(n_agents=G, replay_memory=600, ewc=100.0, ewc_decay=-1.0, ewc_for_critic=1)
+        p = ddrl_amd.DdpgPopulation(cfg, init_seed=3)
+        rng = np.random.RandomState(1)
+        p.set_hyper("alpha_a", 10 ** rng.uniform(-5, -2, G)); p.set_hyper("alpha_v", 10 ** rng.uniform(-5, -2, G))
+        p.seed_replay((77 + np.arange(G)).astype(np.uint32))
+        rows = [synth_rows(k, 600, 18, 6) for k in range(8)]
+        for g in range(G):
+            p.replay_load(g, rows[g % 8])
+        p.update()
+        p.update_best_param(np.ones(G)); p.ewc_setup()
+        pops.append(p)
+    a, b = pops
+    for _ in range(2):
+        a.update_n(n)
+        for _ in range(n):
+            b.update()
+    a.sync()
+    for net in range(4):
+        assert np.array_equal(a.weights(net), b.weights(net)), net
+    for net in (0, 1):
+        for x, y in zip(a.adam(net), b.adam(net)):
+            assert np.array_equal(x, y)
+        sa, sb = a.ewc_state(net), b.ewc_state(net)
+        assert np.array_equal(sa["fisher"], sb["fisher"]) and np.array_equal(sa["fisher_nbr"], sb["fisher_nbr"])
+    la, lb = a.last(), b.last()
+    for k in la:
+        assert np.array_equal(la[k], lb[k]), k
+    assert np.all(a.adam(1)[2] == 1 + 2 * n)
