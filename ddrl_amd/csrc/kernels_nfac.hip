@@ -341,6 +341,68 @@ net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *_
   }
 }
 
+// The same for nets wider than the LDS-resident passes take (DDRL_MAXW < width <= DDRL_WIDE_MAXW; BASELINE.md
+// "large"): one workgroup per (64-row chunk, agent), activations ping-pong through a global scratch block
+// [G x chunks x 2 x 64 x ldw] that stays in L2, one thread per output element, plain fp32 FMA chains over k
+// (this entry point serves inspection and evaluation calls, not the update path: kernels_ddpg_wide.hip).
+__global__ void __launch_bounds__(256)
+net_forward_wide_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out,
+                        float *__restrict__ scratch, int ldw, int n, const float *__restrict__ sgate, int S,
+                        const float *__restrict__ agate, int A, int gate_out) {
+  const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x;
+  const int row0 = chunk * DDRL_MB, d0 = nd.d(0), dl = nd.d(nd.L());
+  float *buf = scratch + ((size_t)agent * gridDim.x + chunk) * 2 * DDRL_MB * ldw;
+  const float *xin = X + (size_t)agent * n * d0;
+  const float *wn = w + (size_t)agent * nd.stride();
+  for (int e = tid; e < DDRL_MB * d0; e += 256) {
+    const int row = e / d0, col = e - row * d0;
+    float v = row0 + row < n ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
+    if (sgate && col < S) v *= sgate[(size_t)agent * S + col];
+    if (agate && !gate_out && col >= S && col < S + A) v *= agate[(size_t)agent * A + col - S];
+    buf[row * ldw + col] = v;
+  }
+  __syncthreads();
+  for (int l = 0; l < nd.L(); ++l) {
+    const float *xi = buf + (l & 1) * DDRL_MB * ldw;
+    float *yo = buf + ((l + 1) & 1) * DDRL_MB * ldw;
+    const int K = nd.d(l), N = nd.d(l + 1), kp = nd.kp(l);
+    const float *Wl = wn + nd.offw(l), *bias = wn + nd.offb(l);
+    const int act = l == nd.L() - 1 ? nd.out_act() : nd.hidden_act();
+    for (int e = tid; e < DDRL_MB * N; e += 256) {
+      const int col = e % N, row = e / N;                  // consecutive threads: consecutive weight rows of one batch row
+      float acc = bias[col];
+      for (int k = 0; k < K; ++k) acc = fmaf(xi[row * ldw + k], Wl[ddrl_widx(col, k, kp)], acc);
+      yo[row * ldw + col] = act_fwd(act, acc);
+    }
+    __syncthreads();                                       // (workgroup-scope fence included: the next layer reads other threads' outputs)
+  }
+  const float *top = buf + (nd.L() & 1) * DDRL_MB * ldw;
+  float *o = out + (size_t)agent * n * dl;
+  for (int e = tid; e < DDRL_MB * dl; e += 256) {
+    const int row = e / dl, col = e - row * dl;
+    if (row0 + row < n) {
+      float v = top[row * ldw + col];
+      if (agate && gate_out) v *= agate[(size_t)agent * A + col];
+      o[(size_t)(row0 + row) * dl + col] = v;
+    }
+  }
+}
+
+extern "C" size_t net_forward_wide_scratch_floats(const NetDesc *nd, int n, int G) {
+  int ldw = 4;
+  for (int l = 0; l <= nd->L_; ++l) ldw = std::max(ldw, nd->d_[l]);
+  return (size_t)G * ((n + DDRL_MB - 1) / DDRL_MB) * 2 * DDRL_MB * ldw;
+}
+
+extern "C" hipError_t net_forward_wide_launch(const NetDesc *nd, const float *w, const float *X, float *out, float *scratch, int n,
+                                              int G, const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
+  int ldw = 4;
+  for (int l = 0; l <= nd->L_; ++l) ldw = std::max(ldw, nd->d_[l]);
+  hipLaunchKernelGGL(net_forward_wide_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(256), 0, st, *nd, w, X, out, scratch, ldw,
+                     n, sgate, S, agate, A, gate_out);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
                                          const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
   static LdsConfig conf;

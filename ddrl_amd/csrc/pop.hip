@@ -27,6 +27,9 @@ hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, 
                         const float *in_gate, const float *out_gate, int G, hipStream_t st);
 hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
                               const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
+size_t net_forward_wide_scratch_floats(const NetDesc *nd, int n, int G);
+hipError_t net_forward_wide_launch(const NetDesc *nd, const float *w, const float *X, float *out, float *scratch, int n, int G,
+                                   const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
 hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st);
 hipError_t load_flat_launch(const NetDesc *nd, float *w, const float *flat, int ld, const uint8_t *flag, int G, hipStream_t st);
 hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat, float *nbr,
@@ -565,24 +568,32 @@ extern "C" int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions
 // MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579): n rows per agent through one net
 extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float *x, float *out) {
   if (!h || !x || !out || n < 1 || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
-  for (int l = 0; l < train_net(h, net)->nd.L(); ++l)
-    if (train_net(h, net)->nd.d(l) > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "forward_batch: layers wider than %d are not supported", DDRL_MAXW);
   int rc = set_device(h);
   if (rc) return rc;
   const TrainNet *t = train_net(h, net);
+  bool wide = false;                                       // some layer beyond the LDS-resident passes: the global-scratch kernel
+  for (int l = 0; l <= t->nd.L(); ++l) wide = wide || t->nd.d(l) > DDRL_MAXW;
   const size_t G = h->G, d0 = t->nd.d(0), dl = t->nd.d(t->nd.L());
-  float *dx = nullptr, *dout = nullptr;
+  float *dx = nullptr, *dout = nullptr, *dscr = nullptr;
   HIPCHK(hipMalloc(&dx, G * n * d0 * sizeof(float)));
   if (hipMalloc(&dout, G * n * dl * sizeof(float)) != hipSuccess) { (void)hipFree(dx); return ddrl_fail(DDRL_ENOMEM, "hipMalloc failed"); }
+  if (wide && hipMalloc(&dscr, net_forward_wide_scratch_floats(&t->nd, n, h->G) * sizeof(float)) != hipSuccess) {
+    (void)hipFree(dx); (void)hipFree(dout);
+    return ddrl_fail(DDRL_ENOMEM, "hipMalloc failed");
+  }
   const bool actor = net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET;
+  const float *sg = h->gates_on ? h->d_sgate : nullptr, *ag = h->gates_on ? h->d_agate : nullptr;
   hipError_t e = hipMemcpyAsync(dx, x, G * n * d0 * sizeof(float), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess)
-    e = net_forward_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, h->gates_on ? h->d_sgate : nullptr, h->cfg.nb_sensors,
-                           h->gates_on ? h->d_agate : nullptr, h->cfg.nb_motors, actor ? 1 : 0, h->stream);
+    e = wide ? net_forward_wide_launch(&t->nd, net_weights(h, net), dx, dout, dscr, n, h->G, sg, h->cfg.nb_sensors, ag,
+                                       h->cfg.nb_motors, actor ? 1 : 0, h->stream)
+             : net_forward_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, sg, h->cfg.nb_sensors, ag, h->cfg.nb_motors,
+                                  actor ? 1 : 0, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out, dout, G * n * dl * sizeof(float), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(dx);
   (void)hipFree(dout);
+  if (dscr) (void)hipFree(dscr);
   if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "forward_batch: %s", hipGetErrorString(e));
   return DDRL_OK;
 }

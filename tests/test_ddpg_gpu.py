@@ -259,10 +259,11 @@ def test_ewc_lifecycle_matches_oracle(ora, hidden, for_critic):
             assert st["decay_mult"][g] == so["decay_mult"]
 
 
-def test_forward_batch_all_nets(ora):
+@pytest.mark.parametrize("hidden_a,hidden_q", [((64, 33), (100, 100)), ((400, 300), (160, 129))])   # the second: wider than the LDS-resident passes
+def test_forward_batch_all_nets(ora, hidden_a, hidden_q):
     """MLP::computeOutBatch / computeOutVFBatch (MLP.hpp:531-579): n rows per agent, n not a multiple of 64."""
     G, S, A = 3, 18, 6
-    pop, agents = make_pair(ora, G=G, hidden_a=(64, 33), hidden_q=(100, 100), wscale=0.2, seed=3)
+    pop, agents = make_pair(ora, G=G, hidden_a=hidden_a, hidden_q=hidden_q, wscale=0.05 if max(hidden_a) > 128 else 0.2, seed=3)
     rng = np.random.RandomState(7)
     for n in (1, 64, 150):
         xs = rng.uniform(-1, 1, (G, n, S)).astype(np.float32)
