@@ -8,6 +8,7 @@
 // exploration noise (SURVEY.md 8a row a32 keeps it on the host).  Every net evaluation, replay
 // insertion and update goes through the ddrl_pop_* entry points, i.e. runs on the GPU.
 #include "pop_host.h"
+#include "pool.h"
 
 #include <memory>
 #include <sstream>
@@ -62,6 +63,7 @@ struct ddrl_agents {
   std::vector<float> last_state, last_action, last_pure, returned_ac, pure, rew;   // [G x S], [G x A] x 4, [G]
   std::vector<uint8_t> insert_mask, goal;
   std::vector<double> ret_double;            // DDPGAg_run's return buffer (valid until the next call)
+  std::unique_ptr<DdrlPool> pool;            // per-agent host work of a step (exploration noise) for large populations
 };
 
 // N(mu, sigma) truncated to [a, b].  The reference calls Chopin's table-driven rtnorm
@@ -613,7 +615,12 @@ extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const floa
       if ((rc = ddrl_nfac_traj_append(h->pop, h->last_state.data(), h->last_pure.data(), h->last_action.data(), states,
                                       h->rew.data(), h->goal.data(), h->insert_mask.data()))) return rc;
     }
-    for (int g = 0; g < G; ++g) {
+    // per-agent host work: every agent has its own noise engine, so blocks of agents go to the pool
+    // (same results whatever the thread count)
+    if (G >= 256 && !h->pool) h->pool.reset(new DdrlPool((int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    constexpr int BLK = 32;
+    auto block = [&](int b) {
+    for (int g = b * BLK; g < std::min(G, (b + 1) * BLK); ++g) {
       if (!decide[g]) continue;
       AgentState &s = h->ag[g];
       float *act = &h->returned_ac[(size_t)g * A];
@@ -633,6 +640,10 @@ extern "C" int ddrl_agents_run(ddrl_agents_t *h, const float *reward, const floa
       s.sum_reward += s.last_receive_reward;
       s.global_pow_gamma *= h->gamma;
     }
+    };
+    const int nblk = (G + BLK - 1) / BLK;
+    if (h->pool) h->pool->run(nblk, block);
+    else for (int b = 0; b < nblk; ++b) block(b);
   }
   memcpy(actions_out, h->returned_ac.data(), (size_t)G * A * sizeof(float));
   return DDRL_OK;

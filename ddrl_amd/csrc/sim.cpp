@@ -9,6 +9,7 @@
 // C callbacks, one environment instance per agent, each driven by one thread at a time.
 #include "../../include/ddrl_pop.h"
 #include "host_util.h"
+#include "pool.h"
 
 #include <errno.h>
 #include <sys/stat.h>
@@ -22,56 +23,6 @@
 #include <mutex>
 #include <thread>
 
-namespace {
-
-// fork-join over [0, n): the calling thread takes part; workers sleep between calls
-class Pool {
- public:
-  explicit Pool(int threads) {
-    for (int t = 1; t < threads; ++t) workers_.emplace_back([this] { loop(); });
-  }
-  ~Pool() {
-    { std::lock_guard<std::mutex> l(m_); stop_ = true; ++epoch_; }
-    cv_.notify_all();
-    for (auto &w : workers_) w.join();
-  }
-  void run(int n, const std::function<void(int)> &f) {
-    if (workers_.empty() || n < 2) { for (int i = 0; i < n; ++i) f(i); return; }
-    { std::lock_guard<std::mutex> l(m_); f_ = &f; n_ = n; next_ = 0; pending_ = (int)workers_.size(); ++epoch_; }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [this] { return pending_ == 0; });
-    f_ = nullptr;
-  }
-
- private:
-  void work() { for (int i; (i = next_.fetch_add(1)) < n_;) (*f_)(i); }
-  void loop() {
-    unsigned long seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return epoch_ != seen; });
-        seen = epoch_;
-        if (stop_) return;
-      }
-      work();
-      { std::lock_guard<std::mutex> l(m_); --pending_; }
-      done_.notify_one();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_, done_;
-  const std::function<void(int)> *f_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, pending_ = 0;
-  unsigned long epoch_ = 0;
-  bool stop_ = false;
-};
-
-}  // namespace
 
 struct ddrl_sim {
   ddrl_agents_t *agents = nullptr;      // borrowed
@@ -83,7 +34,7 @@ struct ddrl_sim {
   bool display_learning = true, can_continue = false;
   std::string out_dir;
   long starting_episode = 0;
-  std::unique_ptr<Pool> pool;
+  std::unique_ptr<DdrlPool> pool;
   // per-tick batches
   std::vector<float> states, rewards, actions;
   std::vector<double> percept, act_d;
@@ -129,7 +80,7 @@ extern "C" int ddrl_sim_create(ddrl_agents_t *agents, const ddrl_env_vtable *env
     if (mkdir(agent_dir(s.get(), g).c_str(), 0777) != 0 && errno != EEXIST)
       return ddrl_fail(DDRL_EIO, "cannot create %s", agent_dir(s.get(), g).c_str());
   if (n_threads < 1) n_threads = 1;
-  s->pool.reset(new Pool(std::min(n_threads, s->G)));
+  s->pool.reset(new DdrlPool(std::min(n_threads, s->G)));
   const size_t G = s->G;
   s->states.assign(G * s->S, 0.f); s->rewards.assign(G, 0.f); s->actions.assign(G * s->A, 0.f);
   s->percept.assign(G * s->S, 0.); s->act_d.assign(G * s->A, 0.);
