@@ -78,21 +78,28 @@ struct Ckpt {
     }
     return payload(v.data(), nb);
   }
-  // device memory, through a host staging buffer on the object's stream
+  // device memory, through a bounded host staging buffer on the object's stream (a population's replay
+  // rings are gigabytes: they move in 64-MiB pieces)
   int dev(const char *tag, void *d, size_t n) {
     uint64_t nb = n;
     int rc = head(tag, &nb, true);
     if (rc || n == 0) return rc;
     if (!d) return ddrl_fail(DDRL_ESTATE, "checkpoint: no device buffer for record '%s'", tag);
-    stage.resize(n);
-    if (writing) {
-      if (hipMemcpyAsync(stage.data(), d, n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return ddrl_fail(DDRL_EHIP, "checkpoint: device read of '%s' failed", tag);
-      return payload(stage.data(), n);
+    const size_t piece = (size_t)64 << 20;
+    stage.resize(n < piece ? n : piece);
+    for (size_t off = 0; off < n; off += piece) {
+      const size_t m = n - off < piece ? n - off : piece;
+      char *dp = (char *)d + off;
+      if (writing) {
+        if (hipMemcpyAsync(stage.data(), dp, m, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+          return ddrl_fail(DDRL_EHIP, "checkpoint: device read of '%s' failed", tag);
+        if ((rc = payload(stage.data(), m))) return rc;
+      } else {
+        if ((rc = payload(stage.data(), m))) return rc;
+        if (hipMemcpyAsync(dp, stage.data(), m, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+          return ddrl_fail(DDRL_EHIP, "checkpoint: device write of '%s' failed", tag);
+      }
     }
-    if ((rc = payload(stage.data(), n))) return rc;
-    if (hipMemcpyAsync(d, stage.data(), n, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-      return ddrl_fail(DDRL_EHIP, "checkpoint: device write of '%s' failed", tag);
     return DDRL_OK;
   }
   // a value that must be the same in the file and in the receiving object (shape, algorithm, sizes)

@@ -429,8 +429,10 @@ int ddrl_agents_cmaes_state(ddrl_agents_t *h, int *lambda, int *n_evaluated, int
  * schedule and the termination history; for the agent front ends additionally every agent's episode /
  * step counters, returns, pending action and exploration-noise engine.
  * load_previous_run fills a handle CREATED WITH THE SAME SHAPES (algorithm, G, nets, minibatch, replay
- * capacity; lambda and N for CMA-ES): anything else is refused with DDRL_EIO before the handle is
- * touched.  Host byte order and layout: a file resumes on the same kind of machine. */
+ * capacity; lambda and N for CMA-ES): a file of another shape or a foreign file is refused with DDRL_EIO
+ * before the handle is touched; a file that turns out truncated or damaged further in also fails with
+ * DDRL_EIO, and the handle then holds a mix until a load succeeds.  Host byte order and layout: a file
+ * resumes on the same kind of machine. */
 int ddrl_pop_save_run(ddrl_pop_t *h, const char *path);
 int ddrl_pop_load_previous_run(ddrl_pop_t *h, const char *path);
 int ddrl_cmaes_save_run(ddrl_cmaes_t *h, const char *path);

@@ -105,6 +105,31 @@ def test_run_files_of_another_shape_are_refused(tmp_path):
     assert np.array_equal(a.weights(1), w)
 
 
+def test_large_population_file_moves_in_pieces(tmp_path):
+    """replay rings beyond the 64-MiB staging buffer of the record stream"""
+    import ddrl_amd
+    G = 256
+    mk = lambda seed: ddrl_amd.DdpgPopulation(ddrl_amd.DdpgConfig(n_agents=G, replay_memory=3000, hidden_unit_a=(20,), hidden_unit_q=(50, 7)),
+                                              init_seed=seed)
+    a = mk(1)
+    rows = [synth_transitions(np.random.RandomState(k), 3000, 18, 6) for k in range(4)]
+    for g in range(G):
+        a.replay_load(g, rows[g % 4][: 2500 + g])
+    a.update_n(3)
+    path = str(tmp_path / "big.run")
+    a.save_run(path)
+    assert os.path.getsize(path) > 128 << 20
+    b = mk(2)
+    b.load_previous_run(path)
+    for p in (a, b):
+        p.update_n(4)
+    for net in range(4):
+        assert np.array_equal(a.weights(net), b.weights(net)), net
+    assert np.array_equal(a.last()["idx"], b.last()["idx"]) and np.array_equal(a.replay_len(), b.replay_len())
+    a.close(); b.close()
+    os.remove(path)
+
+
 def test_nfac_population_resumes_mid_batch(tmp_path):
     """trajectories gathered but not yet learned from travel with the file"""
     import ddrl_amd
