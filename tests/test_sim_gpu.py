@@ -175,3 +175,43 @@ def test_simulator_continue(tmp_path):
         open(bad, "w").write(INI.replace("max_episode={me}\n", "").format(tpe=0, tae=0))
         ddrl_amd.Simulator(again, pe, bad, out)
     s0.close(); s2.close(); full.close(); again.close()
+
+
+def test_simulator_with_cmaes_and_td3_agents(tmp_path):
+    """the same loop over the other front ends: CMAESAg (one individual per environment, one generation per
+    learning episode; its own dump line) and TD3Ag"""
+    import ddrl_amd
+    from test_cmaes_agents_gpu import write_ini as cmaes_ini
+    S, A = 3, 4
+    ini = cmaes_ini(tmp_path, lam=8)
+    open(ini, "a").write("\n[simulation]\nmax_episode=3\ntest_episode_per_episode=0\ntest_episode_at_end=1\ndump_log_each=1\n"
+                         "display_log_each=10\nsave_agent_each=100\n")
+    ag = ddrl_amd.CmaesAgents(ini, S, A, seed=2)
+    envs = [PointEnv(g, S, A) for g in range(ag.G)]
+    out = os.path.join(str(tmp_path), "cm")
+    sim = ddrl_amd.Simulator(ag, envs, ini, out, n_threads=3)
+    sim.run()
+    assert ag.state()["generations"] == 3
+    for g in range(ag.G):
+        lines = open(os.path.join(out, str(g), "0.learning.data")).read().splitlines()
+        assert len(lines) == 3 and len(lines[0].split()) == 5          # episode steps sum_weighted_reward <env fields>
+        assert len(open(os.path.join(out, str(g), "0.0.testing.data")).read().splitlines()) == 1
+    sim.close(); ag.close()
+
+    from test_td3_agents_gpu import write_ini as td3_ini
+    ini = td3_ini(tmp_path, pn=0.1, pf=2)
+    open(ini, "a").write("\n[simulation]\nmax_episode=4\ntest_episode_per_episode=0\ntest_episode_at_end=0\ndump_log_each=2\n"
+                         "display_log_each=10\nsave_agent_each=100\n")
+    G = 4
+    a, b = ddrl_amd.Td3Agents(ini, G, S, A, seed=5), ddrl_amd.Td3Agents(ini, G, S, A, seed=5)
+    ea, eb = [PointEnv(g, S, A) for g in range(G)], [PointEnv(g, S, A) for g in range(G)]
+    out = os.path.join(str(tmp_path), "td3")
+    sim = ddrl_amd.Simulator(a, ea, ini, out, n_threads=2)
+    sim.run()
+    for episode in range(4):
+        reference_loop(b, eb, True, G)
+    for net in range(6):
+        assert np.array_equal(a.pop.weights(net), b.pop.weights(net)), net
+    assert a.pop.adam(1)[2][0] > 100 and a.pop.adam(0)[2][0] < a.pop.adam(1)[2][0]
+    assert len(open(os.path.join(out, "0", "0.learning.data")).read().splitlines()) == 2      # dump_log_each = 2: episodes 0 and 2
+    sim.close(); a.close(); b.close()
