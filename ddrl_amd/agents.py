@@ -14,6 +14,9 @@ class _Borrowed(Population):
 
     def __init__(self, L, handle, G, S, A):
         self.L, self.h, self.G, self.S, self.A = L, handle, G, S, A
+        b = C.c_int()
+        _l.check(L.ddrl_pop_shape(handle, None, None, None, None, C.byref(b)))
+        self.B = b.value
 
     def close(self):
         self.h = None

@@ -372,6 +372,16 @@ extern "C" int ddrl_pop_destroy(ddrl_pop_t *h) {
   return DDRL_OK;
 }
 
+extern "C" int ddrl_pop_shape(ddrl_pop_t *h, int *kind, int *n_agents, int *nb_sensors, int *nb_motors, int *mini_batch_size) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  if (kind) *kind = h->algo == 0 && h->nnets == 3 ? 3 : h->algo;
+  if (n_agents) *n_agents = h->G;
+  if (nb_sensors) *nb_sensors = h->cfg.nb_sensors;
+  if (nb_motors) *nb_motors = h->cfg.nb_motors;
+  if (mini_batch_size) *mini_batch_size = h->algo == 0 ? h->cfg.mini_batch_size : 0;
+  return DDRL_OK;
+}
+
 extern "C" int ddrl_pop_sync(ddrl_pop_t *h) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("ddrl_ddpg_create", _i, [C.POINTER(DdpgConfigC), C.c_uint64, C.POINTER(_vp)]),
     ("ddrl_pop_destroy", _i, [_vp]),
     ("ddrl_pop_sync", _i, [_vp]),
+    ("ddrl_pop_shape", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("ddrl_pop_set_hyper", _i, [_vp, _cp, _vp]),
     ("ddrl_pop_num_params", _i, [_vp, _i]),
     ("ddrl_pop_set_weights", _i, [_vp, _i, _vp]),

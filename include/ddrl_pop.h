@@ -93,6 +93,9 @@ int ddrl_ddpg_config_from_ini(const char *path, ddrl_ddpg_config *cfg);
 int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed, ddrl_pop_t **out);
 int ddrl_pop_destroy(ddrl_pop_t *h);
 int ddrl_pop_sync(ddrl_pop_t *h);
+/* what a handle holds: kind 0 DDPG, 1 NFAC, 2 policies only, 3 TD3; minibatch = 0 where there is none.
+ * Any pointer may be NULL. */
+int ddrl_pop_shape(ddrl_pop_t *h, int *kind, int *n_agents, int *nb_sensors, int *nb_motors, int *mini_batch_size);
 
 /* per-agent hyper-parameters: key in {"alpha_a","alpha_v","tau_soft_update","gamma","decay_v"} */
 int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *per_agent /* [G] */);

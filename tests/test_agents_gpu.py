@@ -205,3 +205,69 @@ def test_reference_c_flavour(tmp_path):
             x.close()
     finally:
         os.chdir(cwd)
+
+
+def test_config1_cartpole_plumbing(ora, tmp_path):
+    """cartpole dims (S=4, A=1), one agent, the nets / minibatch / force_more_update of the
+    reference's agent/deepqn/data/ddpg-cp.ini (q=50,7 a=20, B=512, 8 passes of the fupd loop per stored transition),
+    synthetic transitions s ~ U(-1,1)^4.  The first update round is held to the oracle (indices bit-exact); then the
+    run goes on to 1500 steps: update counts exact, weights finite."""
+    import ddrl_amd
+    ini = os.path.join(str(tmp_path), "cp.ini")
+    open(ini, "w").write("""[agent]
+gamma=0.99
+decision_each=1
+noise=0.1
+gaussian_policy=0
+hidden_unit_q=50,7
+hidden_unit_a=20
+mini_batch_size=512
+replay_memory=100000
+force_more_update=7
+tau_soft_update=0.001
+alpha_a=0.1
+alpha_v=0.01
+inverting_grad=true
+decay_v=-1
+batch_norm_critic=0
+batch_norm_actor=0
+actor_output_layer_type=2
+hidden_layer_type=1
+test_net=false
+bn_adapt=false
+momentum=0
+nstep_return=0
+""")
+    S, A, B, seed = 4, 1, 512, 21
+    ag = ddrl_amd.DdpgAgents(ini, 1, S, A, seed=seed)
+    rng = np.random.RandomState(0)
+    wa = rng.normal(0, 0.1, (1, ag.pop.num_params(0))).astype(np.float32).astype(np.float64)
+    wq = rng.normal(0, 0.1, (1, ag.pop.num_params(1))).astype(np.float32).astype(np.float64)
+    for net, w in ((0, wa), (1, wq), (2, wa), (3, wq)):
+        ag.pop.set_weights(net, w)
+    o = ora.Ddpg(S, A, B, (20,), (50, 7), replay_cap=100000, gamma=0.99, tau=float(np.float32(0.001)), alpha_a=float(np.float32(0.1)),
+                 alpha_v=float(np.float32(0.01)), seed=replay_seed(seed, 0))
+    o.ann.set_weights(wa[0]); o.ann_target.set_weights(wa[0]); o.qnn.set_weights(wq[0]); o.qnn_target.set_weights(wq[0])
+    s = rng.uniform(-1, 1, (1, S)).astype(np.float32)
+    ag.start_episode(s, True)
+    last_s, last_a, rounds = None, None, 0
+    for t in range(1500):
+        r = float(rng.normal())
+        s = rng.uniform(-1, 1, (1, S)).astype(np.float32)
+        act = ag.run(r, s, True, False, False)
+        if last_a is not None and rounds == 0:
+            o.insert(last_s, last_a, float(np.float32(r)), s[0].astype(np.float64), False)
+            if o.replay_len() >= B:                          # the first update round (DeepQNAg.hpp:338-341): 8 passes
+                used = [o.update()[1] for _ in range(8)]
+                assert np.array_equal(ag.pop.last()["idx"][0], used[-1])          # same engine, same 8 x 512 draws
+                for net in range(4):
+                    w, wo = ag.pop.weights(net)[0], o.nets[net].weights()
+                    assert close_frac(w, wo, 1e-3, 0.99, 0.5), net              # alpha_a = 0.1: Adam's sign steps are large
+                rounds = 1
+        last_s, last_a = s[0].astype(np.float64), act[0].astype(np.float64)
+    n_rounds = 1499 - (B - 1)                                # transitions 512 .. 1499 each trigger a round
+    assert ag.pop.replay_len()[0] == 1499
+    assert ag.pop.adam(1)[2][0] == 8 * n_rounds and ag.pop.adam(0)[2][0] == 8 * n_rounds
+    for net in range(4):
+        assert np.all(np.isfinite(ag.pop.weights(net)))
+    ag.close()
