@@ -82,37 +82,38 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
   const float *xrow = X + (16 * wave + c) * ldx;
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const int KC = (kp + 15) >> 4;
-  // fragments of k-chunk kc + 1 are requested before chunk kc is multiplied (the weights come from HBM:
-  // without this every chunk paid a full round trip); two register sets, loop unrolled by two
-  struct Frag { f32x4 a, b[4]; };
-  auto load = [&](int kc, Frag &f) {
+  // The four waves need the same weight fragments (they differ in their batch rows only): wave w fetches tile w
+  // of the k-chunk once and hands it to the others through LDS, double-buffered, one barrier per k-chunk;
+  // chunk kc + 1 travels (global -> registers) while chunk kc is multiplied.
+  __shared__ __align__(16) float sB[2][4][256];
+  auto load_a = [&](int kc) {
+    const int kcc = kc < KC ? kc : KC - 1;
+    const bool in = kcc * 16 + 4 * g < kp;
+    f32x4 a = *(const f32x4 *)(xrow + (in ? kcc * 16 + 4 * g : kp - 4));
+    return in ? a : zero4();
+  };
+  auto load_b = [&](int kc) {              // this wave's tile (t = wave) of chunk kc
     const int kcc = kc < KC ? kc : KC - 1;
     const int kw = ddrl_tile_kw(kcc, kp);
-    const bool in = kcc * 16 + 4 * g < kp;
-    f.a = *(const f32x4 *)(xrow + (in ? kcc * 16 + 4 * g : kp - 4));
-    if (!in) f.a = zero4();
+    const int nt = nb * 4 + wave < (N + 15) / 16 ? nb * 4 + wave : (N + 15) / 16 - 1;     // clamped: tiles beyond N are discarded below
+    const float *blk = Wl + ddrl_tile_base(nt, kcc, kp) + c * kw;
+    return *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
+  };
+  f32x4 a_cur = load_a(0), b_nxt = load_b(0), a_nxt;
+  *(f32x4 *)&sB[0][wave][lane * 4] = b_nxt;
+  for (int kc = 0; kc < KC; ++kc) {
+    const int cur = kc & 1;
+    a_nxt = load_a(kc + 1);
+    b_nxt = load_b(kc + 1);
+    __syncthreads();                       // sB[cur] is complete; nobody reads sB[cur ^ 1] any more
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int nt = nb * 4 + t < (N + 15) / 16 ? nb * 4 + t : (N + 15) / 16 - 1;     // clamped: tiles beyond N are discarded below
-      const float *blk = Wl + ddrl_tile_base(nt, kcc, kp) + c * kw;
-      f.b[t] = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
-    }
-  };
-  auto mul = [&](const Frag &f) {
+      const f32x4 b = *(const f32x4 *)&sB[cur][t][lane * 4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[t] = mfma16(f.a[e], f.b[t][e], acc[t]);
-  };
-  Frag f0, f1;
-  load(0, f0);
-  for (int kc = 0; kc < KC; kc += 2) {
-    load(kc + 1, f1);
-    mul(f0);
-    if (kc + 1 < KC) {
-      load(kc + 2, f0);
-      mul(f1);
+      for (int e = 0; e < 4; ++e) acc[t] = mfma16(a_cur[e], b[e], acc[t]);
     }
+    *(f32x4 *)&sB[cur ^ 1][wave][lane * 4] = b_nxt;
+    a_cur = a_nxt;
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -144,36 +145,40 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
   const float *zrow = dZ + (16 * wave + c) * ldz;
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   const int NC = (N + 15) >> 4, KT = (kp + 15) >> 4;
-  struct Frag { f32x4 a; float b[4][4]; };
-  auto load = [&](int nc, Frag &f) {          // chunk nc + 1 is in flight while chunk nc is multiplied
+  // as in wide_fwd_kernel: wave w fetches the weight fragments of column tile w of the chunk, the others take
+  // them from LDS (double-buffered, one barrier per chunk)
+  __shared__ __align__(16) float sB[2][4][256];
+  auto load_a = [&](int nc) {
     const int ncc = nc < NC ? nc : NC - 1;
     const bool inn = ncc * 16 + 4 * g < n4;    // columns [N, n4) of dZ hold zeros
-    f.a = *(const f32x4 *)(zrow + (inn ? ncc * 16 + 4 * g : n4 - 4));
-    if (!inn) f.a = zero4();
+    f32x4 a = *(const f32x4 *)(zrow + (inn ? ncc * 16 + 4 * g : n4 - 4));
+    return inn ? a : zero4();
+  };
+  auto load_b = [&](int nc) {
+    const int ncc = nc < NC ? nc : NC - 1;
+    const int kt = kb * 4 + wave < KT ? kb * 4 + wave : KT - 1;                          // clamped: discarded below
+    const int kw = ddrl_tile_kw(kt, kp);
+    const float *blk = Wl + ddrl_tile_base(ncc, kt, kp) + 4 * g * kw + (c < kw ? c : kw - 1);   // pad rows (n >= N) hold zeros
+    f32x4 b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = blk[j * kw];
+    return b;
+  };
+  f32x4 a_cur = load_a(0), b_nxt = load_b(0), a_nxt;
+  *(f32x4 *)&sB[0][wave][lane * 4] = b_nxt;
+  for (int nc = 0; nc < NC; ++nc) {
+    const int cur = nc & 1;
+    a_nxt = load_a(nc + 1);
+    b_nxt = load_b(nc + 1);
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int kt = kb * 4 + t < KT ? kb * 4 + t : KT - 1;                            // clamped: discarded below
-      const int kw = ddrl_tile_kw(kt, kp);
-      const float *blk = Wl + ddrl_tile_base(ncc, kt, kp) + 4 * g * kw + (c < kw ? c : kw - 1);   // pad rows (n >= N) hold zeros
+      const f32x4 b = *(const f32x4 *)&sB[cur][t][lane * 4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f.b[t][j] = blk[j * kw];
+      for (int j = 0; j < 4; ++j) acc[t] = mfma16(a_cur[j], b[j], acc[t]);
     }
-  };
-  auto mul = [&](const Frag &f) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t] = mfma16(f.a[j], f.b[t][j], acc[t]);
-  };
-  Frag f0, f1;
-  load(0, f0);
-  for (int nc = 0; nc < NC; nc += 2) {
-    load(nc + 1, f1);
-    mul(f0);
-    if (nc + 1 < NC) {
-      load(nc + 2, f0);
-      mul(f1);
-    }
+    *(f32x4 *)&sB[cur ^ 1][wave][lane * 4] = b_nxt;
+    a_cur = a_nxt;
   }
   const int S = P.S, A = P.A, ldda = ddrl_ldpad(A);
 #pragma unroll
