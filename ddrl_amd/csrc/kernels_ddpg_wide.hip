@@ -196,37 +196,49 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
   }
 }
 
-// dW[64 n x 64 k block] = dZ^T X over the chunk's 64 rows (+ db for the k-block 0), written to the
-// chunk's partial-gradient image (same layout as the weights)
+// dW[64 n-block x all k] = dZ^T X over the chunk's 64 rows (+ db), written to the chunk's partial-gradient
+// image (same layout as the weights).  One workgroup per 64-column block of dZ: the block is staged in LDS
+// once and the 64-column blocks of X stream past it.
 __global__ void __launch_bounds__(256)
 wide_dw_kernel(const DdpgParams P, const WideOp op) {
   __shared__ __align__(16) float sY[DDRL_MB * 68], sX[DDRL_MB * 68];
-  const int chunk = blockIdx.y, agent = blockIdx.z;
+  const int nb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
   if (wide_skip(P, agent, chunk, op.policy)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
   const NetDesc &nd = op.net ? P.q : P.a;
   const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
   const int KB = (kp + 63) >> 6;
-  const int nb = blockIdx.x / KB, kb = blockIdx.x - nb * KB;
   const WideMap W = wide_map(P, agent, chunk);
   float *X, *dZ; int ldx, ldz;
   wide_io(P, W, op.net, l, nd, X, ldx, dZ, ldz);
-  for (int e = tid; e < DDRL_MB * 64; e += 256) {
-    const int row = e >> 6, col = e & 63;
-    sY[row * 68 + col] = nb * 64 + col < N ? dZ[row * ldz + nb * 64 + col] : 0.f;
-    sX[row * 68 + col] = kb * 64 + col < kp ? X[row * ldx + kb * 64 + col] : 0.f;
-  }
-  __syncthreads();
-  const int Nloc = N - nb * 64 < 64 ? N - nb * 64 : 64, kploc = kp - kb * 64 < 64 ? kp - kb * 64 : 64;
+  // 16-byte pieces: row strides and block offsets are multiples of 4 floats; columns [N, ldz) / [kp, ldx) hold zeros
+  auto stage = [&](float *dst, const float *src, int ld, int col0, int width) {
+    for (int e = tid; e < DDRL_MB * 16; e += 256) {
+      const int row = e >> 4, c4 = (e & 15) * 4;
+      f32x4 v = zero4();
+      if (col0 + c4 < width) v = *(const f32x4 *)(src + row * ld + col0 + c4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (col0 + c4 + j >= width) v[j] = 0.f;
+      *(f32x4 *)(dst + row * 68 + c4) = v;
+    }
+  };
+  stage(sY, dZ, ldz, nb * 64, N);
+  const int Nloc = N - nb * 64 < 64 ? N - nb * 64 : 64;
   float *gout = (op.net == 2 ? P.gpart_q2 : op.net ? P.gpart_q : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb) __syncthreads();               // every wave is done with the previous block of X
+    stage(sX, X, ldx, kb * 64, kp);
+    __syncthreads();
+    const int kploc = kp - kb * 64 < 64 ? kp - kb * 64 : 64;
 #pragma unroll 1
-  for (int t = 0; t < 4; ++t) {
-    const int p = wave * 4 + t;
-    const f32x4 acc = dw_tile(sY, 68, Nloc, sX, 68, kploc, p, 16, 4, c, g);
-    const int n = nb * 64 + (p >> 2) * 16 + c, k = kb * 64 + (p & 3) * 16 + 4 * g;
-    if (n < N && k < kp) *(f32x4 *)(gout + nd.offw(l) + ddrl_widx(n, k, kp)) = acc;
+    for (int t = 0; t < 4; ++t) {
+      const int p = wave * 4 + t;
+      const f32x4 acc = dw_tile(sY, 68, Nloc, sX, 68, kploc, p, 16, 4, c, g);
+      const int n = nb * 64 + (p >> 2) * 16 + c, k = kb * 64 + (p & 3) * 16 + 4 * g;
+      if (n < N && k < kp) *(f32x4 *)(gout + nd.offw(l) + ddrl_widx(n, k, kp)) = acc;
+    }
   }
-  if (kb == 0 && tid < 64 && nb * 64 + tid < N) gout[nd.offb(l) + nb * 64 + tid] = bias_grad(sY, 68, tid);
+  if (tid < 64 && nb * 64 + tid < N) gout[nd.offb(l) + nb * 64 + tid] = bias_grad(sY, 68, tid);
 }
 
 // the element-wise steps between the layer launches, one workgroup per (chunk, agent)
@@ -354,7 +366,7 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
   auto dw = [&](int net, int l) {
     const NetDesc &nd = net ? P.q : P.a;
     const WideOp op = {net, 0, l, 0, policy};
-    hipLaunchKernelGGL(wide_dw_kernel, dim3(((nd.d_[l + 1] + 63) / 64) * ((nd.kp_[l] + 63) / 64), C, G), dim3(256), 0, st, P, op);
+    hipLaunchKernelGGL(wide_dw_kernel, dim3((nd.d_[l + 1] + 63) / 64, C, G), dim3(256), 0, st, P, op);
   };
   hipError_t e;
   if (td3) {
