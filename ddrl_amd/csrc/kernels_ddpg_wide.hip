@@ -11,13 +11,14 @@
 struct WideMap {
   LdsMap M;              // the fused kernel's tiles, here pointers into the scratch block
   float *ha, *hq, *da;   // hidden activations of the actor / critic pass, raw dQ/da [64 x ldpad(A)]
+  float *dz;             // dZ_l of the hidden layers of the backward pass in flight: the activations stay intact for dW
   int hstride;
 };
 
 __host__ __device__ inline size_t wide_block_floats(const DdpgParams &P) {
   const int A = P.a.d_[P.a.L_];
   size_t f = (size_t)DDRL_MB * (P.ldxc + P.ldxa + P.q.ld_[P.q.L_] + P.a.ld_[P.a.L_] + 5 + ddrl_ldpad(A));
-  f += (size_t)(P.a.L_ - 1 + P.q.L_ - 1) * DDRL_MB * P.ldh;
+  f += (size_t)(P.a.L_ - 1 + P.q.L_ - 1 + (P.a.L_ > P.q.L_ ? P.a.L_ : P.q.L_) - 1) * DDRL_MB * P.ldh;
   return (f + 63) / 64 * 64;
 }
 
@@ -38,7 +39,8 @@ __device__ __forceinline__ WideMap wide_map(const DdpgParams &P, int agent, int 
   W.da = p; p += DDRL_MB * ddrl_ldpad(A);
   W.hstride = DDRL_MB * P.ldh;
   W.ha = p; p += (P.a.L() - 1) * W.hstride;
-  W.hq = p;
+  W.hq = p; p += (P.q.L() - 1) * W.hstride;
+  W.dz = p;
   return W;
 }
 
@@ -62,6 +64,11 @@ __device__ __forceinline__ void wide_io(const DdpgParams &P, const WideMap &W, i
   const bool last = l == nd.L() - 1;
   out = last ? (net ? W.M.topq : W.M.topa) : h + l * W.hstride;
   ldo = nd.ld(l + 1);
+}
+// where the backward pass keeps dZ_l (gradient at layer l's pre-activation output): the top tile for the last
+// layer (the loss steps write it there), a buffer of its own below
+__device__ __forceinline__ float *wide_dz(const WideMap &W, int net, int l, const NetDesc &nd) {
+  return l == nd.L() - 1 ? (net ? W.M.topq : W.M.topa) : W.dz + l * W.hstride;
 }
 
 // Y[64 x N] = act(X W^T + b): one 64-column block of outputs per workgroup, wave w owns rows 16w..16w+15
@@ -126,9 +133,10 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
   }
 }
 
-// dX[64 x 64-column block] = dZ W for layer l.  mode 0: the block of H_{l-1} becomes dZ_{l-1} in
-// place (derivative taken from the activation's output, MLP.hpp:799-803).  mode 1 (layer 0 of the
-// critic): the action columns [S, S + A) go to W.da untouched.
+// dX[64 x 64-column block] = dZ W for layer l.  mode 0: dZ_{l-1} = dX x the derivative of layer l-1's
+// activation, taken from its output H_{l-1} (MLP.hpp:799-803), into the dZ buffer -- H_{l-1} stays intact: the
+// dW kernel of layer l reads it AFTER this kernel, because with a one-chunk minibatch it updates W_l in place.
+// mode 1 (layer 0 of the critic): the action columns [S, S + A) go to W.da untouched.
 __global__ void __launch_bounds__(256)
 wide_dx_kernel(const DdpgParams P, const WideOp op) {
   const int kb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
@@ -141,6 +149,7 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
   const WideMap W = wide_map(P, agent, chunk);
   float *in, *dZ; int ldi, ldz;
   wide_io(P, W, op.net, l, nd, in, ldi, dZ, ldz);
+  dZ = wide_dz(W, op.net, l, nd);
   const int n4 = ddrl_roundup(N, 4);
   const float *zrow = dZ + (16 * wave + c) * ldz;
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
@@ -188,7 +197,7 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * wave + 4 * g + r;
       if (op.mode == 0) {
-        if (col < K) in[row * ldi + col] = act_bwd(nd.hidden_act(), in[row * ldi + col], acc[t][r]);
+        if (col < kp) wide_dz(W, op.net, l - 1, nd)[row * ldi + col] = col < K ? act_bwd(nd.hidden_act(), in[row * ldi + col], acc[t][r]) : 0.f;
       } else if (col >= S && col < S + A) {
         W.da[row * ldda + col - S] = acc[t][r];
       }
@@ -211,6 +220,7 @@ wide_dw_kernel(const DdpgParams P, const WideOp op) {
   const WideMap W = wide_map(P, agent, chunk);
   float *X, *dZ; int ldx, ldz;
   wide_io(P, W, op.net, l, nd, X, ldx, dZ, ldz);
+  dZ = wide_dz(W, op.net, l, nd);
   // 16-byte pieces: row strides and block offsets are multiples of 4 floats; columns [N, ldz) / [kp, ldx) hold zeros
   auto stage = [&](float *dst, const float *src, int ld, int col0, int width) {
     for (int e = tid; e < DDRL_MB * 16; e += 256) {
@@ -374,7 +384,7 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     step(0); fwd(0, 1); step(6); fwd(1, 1); step(7); fwd(2, 1); step(8);
     for (int k = 1; k <= 2; ++k) {
       fwd(k, 0); step(k == 1 ? 3 : 9);
-      for (int l = P.q.L_ - 1; l >= 0; --l) { dw(k, l); if (l > 0) dx(k, l, 0); }
+      for (int l = P.q.L_ - 1; l >= 0; --l) { if (l > 0) dx(k, l, 0); dw(k, l); }
       WIDE_CHECK();
       if ((e = ddpg_apply_launch(Pp, k, st)) != hipSuccess) return e;
     }
@@ -384,13 +394,13 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     for (int l = P.q.L_ - 1; l >= 1; --l) dx(1, l, 0);
     dx(1, 0, 1);
     step(5);
-    for (int l = P.a.L_ - 1; l >= 0; --l) { dw(0, l); if (l > 0) dx(0, l, 0); }
+    for (int l = P.a.L_ - 1; l >= 0; --l) { if (l > 0) dx(0, l, 0); dw(0, l); }
     WIDE_CHECK();
     return ddpg_apply_launch(Pp, 0, st);
   }
   // critic: y = r + gamma Q'(s', pi'(s')), then learn_batch (DeepQNAg.hpp:379-408)
   step(0); fwd(0, 1); step(1); fwd(1, 1); step(2); fwd(1, 0); step(3);
-  for (int l = P.q.L_ - 1; l >= 0; --l) { dw(1, l); if (l > 0) dx(1, l, 0); }
+  for (int l = P.q.L_ - 1; l >= 0; --l) { if (l > 0) dx(1, l, 0); dw(1, l); }
   WIDE_CHECK();
   if ((e = ddpg_apply_launch(Pp, 1, st)) != hipSuccess) return e;
   // actor: dQ/da through the NEW critic, inverting gradients, actor backward (:411-459)
@@ -398,7 +408,7 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
   for (int l = P.q.L_ - 1; l >= 1; --l) dx(1, l, 0);
   dx(1, 0, 1);
   step(5);
-  for (int l = P.a.L_ - 1; l >= 0; --l) { dw(0, l); if (l > 0) dx(0, l, 0); }
+  for (int l = P.a.L_ - 1; l >= 0; --l) { if (l > 0) dx(0, l, 0); dw(0, l); }
   WIDE_CHECK();
   return ddpg_apply_launch(Pp, 0, st);
 }
