@@ -208,6 +208,11 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
 // dW[64 n-block x all k] = dZ^T X over the chunk's 64 rows (+ db), written to the chunk's partial-gradient
 // image (same layout as the weights).  One workgroup per 64-column block of dZ: the block is staged in LDS
 // once and the 64-column blocks of X stream past it.
+// FUSE (one-chunk minibatches: the chunk's gradient IS the minibatch gradient): every tile goes from the MFMA
+// accumulator straight through the optimiser epilogue of the fused kernel (opt_load4 / opt_step4: Fisher EMA,
+// EWC penalty, L2, Adam, soft target update) -- no partial-gradient image, no apply launch; the tile's state
+// is requested before its products.  The layer's input-gradient kernel has run before (old weights).
+template <bool FUSE, bool EWC>
 __global__ void __launch_bounds__(256)
 wide_dw_kernel(const DdpgParams P, const WideOp op) {
   __shared__ __align__(16) float sY[DDRL_MB * 68], sX[DDRL_MB * 68];
@@ -234,7 +239,14 @@ wide_dw_kernel(const DdpgParams P, const WideOp op) {
   };
   stage(sY, dZ, ldz, nb * 64, N);
   const int Nloc = N - nb * 64 < 64 ? N - nb * 64 : 64;
-  float *gout = (op.net == 2 ? P.gpart_q2 : op.net ? P.gpart_q : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
+  float *gout = FUSE ? nullptr : (op.net == 2 ? P.gpart_q2 : op.net ? P.gpart_q : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
+  OptCtx o = {};
+  if (FUSE) {
+    // TD3 (the only caller that sets actor_step): the critics' targets move on a policy step only (tau = 0 in between)
+    const bool pstep = P.actor_step ? P.actor_step[agent] != 0 : true;
+    const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
+    o = make_opt<EWC>(P, st, nd.stride(), agent, pstep ? P.tau[agent] : 0.f, pstep ? P.omtau[agent] : 1.f, (float)P.B);
+  }
   for (int kb = 0; kb < KB; ++kb) {
     if (kb) __syncthreads();               // every wave is done with the previous block of X
     stage(sX, X, ldx, kb * 64, kp);
@@ -243,12 +255,21 @@ wide_dw_kernel(const DdpgParams P, const WideOp op) {
 #pragma unroll 1
     for (int t = 0; t < 4; ++t) {
       const int p = wave * 4 + t;
-      const f32x4 acc = dw_tile(sY, 68, Nloc, sX, 68, kploc, p, 16, 4, c, g);
       const int n = nb * 64 + (p >> 2) * 16 + c, k = kb * 64 + (p & 3) * 16 + 4 * g;
-      if (n < N && k < kp) *(f32x4 *)(gout + nd.offw(l) + ddrl_widx(n, k, kp)) = acc;
+      const bool ok = n < N && k < kp;
+      const int i = ok ? nd.offw(l) + ddrl_widx(n, k, kp) : nd.offw(l);      // (clamped: the state loaded there is ignored)
+      OptRegs r;
+      if (FUSE) opt_load4<EWC, true>(o, i, r);
+      const f32x4 acc = dw_tile(sY, 68, Nloc, sX, 68, kploc, p, 16, 4, c, g);
+      if (FUSE) opt_step4<EWC, true>(o, i, acc, r, ok);
+      else if (ok) *(f32x4 *)(gout + i) = acc;
     }
   }
-  if (tid < 64 && nb * 64 + tid < N) gout[nd.offb(l) + nb * 64 + tid] = bias_grad(sY, 68, tid);
+  if (tid < 64 && nb * 64 + tid < N) {
+    const float db = bias_grad(sY, 68, tid);
+    if (FUSE) opt_step<EWC, true>(o, nd.offb(l) + nb * 64 + tid, db);
+    else gout[nd.offb(l) + nb * 64 + tid] = db;
+  }
 }
 
 // the element-wise steps between the layer launches, one workgroup per (chunk, agent)
@@ -299,6 +320,14 @@ wide_step_kernel(const DdpgParams P, int step, int policy) {
     }
   } else if (step == 4) {                // DPG seed (:424-428), NOT / B
     if (tid < DDRL_MB) M.topq[tid * ldq] = tid < nrows ? -1.0f : 0.f;
+  } else if (step >= 10 && step <= 12) { // one-chunk minibatches (optimiser fused into the dW kernels): Solver::iter, Fisher count, loss
+    const int net = step - 10;
+    const NetState &st = net == 2 ? P.sq2 : net ? P.sq : P.sa;
+    if (chunk == 0 && tid == 0) {
+      st.iter[agent] += 1;
+      if (st.fisher) st.fisher_nbr[agent] = st.fisher_nbr[agent] * P.fisher_beta + (float)B;
+      if (net >= 1) (net == 1 ? P.loss_out : P.loss2_out)[agent] = (net == 1 ? P.loss_part : P.loss_part2)[(size_t)agent * P.maxchunks] / (float)B * 0.5f;
+    }
   } else if (step == 6) {                // TD3: a' = clip(a' + eps, -1, 1) between the two gates (TD3Ag.hpp:307-309)
     const float *noise = P.noise + ((size_t)agent * B + row0) * A;
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
@@ -373,10 +402,21 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     const WideOp op = {net, 0, l, mode, policy};
     hipLaunchKernelGGL(wide_dx_kernel, dim3((nd.kp_[l] + 63) / 64, C, G), dim3(256), 0, st, P, op);
   };
+  const bool fuse = C == 1;               // one chunk: the optimiser runs inside the dW kernels, no apply launch
   auto dw = [&](int net, int l) {
     const NetDesc &nd = net ? P.q : P.a;
     const WideOp op = {net, 0, l, 0, policy};
-    hipLaunchKernelGGL(wide_dw_kernel, dim3((nd.d_[l + 1] + 63) / 64, C, G), dim3(256), 0, st, P, op);
+    const dim3 grid((nd.d_[l + 1] + 63) / 64, C, G);
+    const bool ewc = (net == 2 ? P.sq2 : net ? P.sq : P.sa).fisher != nullptr;
+    if (!fuse) hipLaunchKernelGGL((wide_dw_kernel<false, false>), grid, dim3(256), 0, st, P, op);
+    else if (ewc) hipLaunchKernelGGL((wide_dw_kernel<true, true>), grid, dim3(256), 0, st, P, op);
+    else hipLaunchKernelGGL((wide_dw_kernel<true, false>), grid, dim3(256), 0, st, P, op);
+  };
+  // after a net's backward pass: the apply kernel over the chunk partials, or the fused path's bookkeeping
+  auto finish = [&](int net) -> hipError_t {
+    if (!fuse) return ddpg_apply_launch(Pp, net, st);
+    step(10 + net);
+    return hipGetLastError();
   };
   hipError_t e;
   if (td3) {
@@ -386,7 +426,7 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
       fwd(k, 0); step(k == 1 ? 3 : 9);
       for (int l = P.q.L_ - 1; l >= 0; --l) { if (l > 0) dx(k, l, 0); dw(k, l); }
       WIDE_CHECK();
-      if ((e = ddpg_apply_launch(Pp, k, st)) != hipSuccess) return e;
+      if ((e = finish(k)) != hipSuccess) return e;
     }
     if (!any_actor) return hipSuccess;
     policy = 1;                                             // the delayed actor update through the first critic (:333-363)
@@ -396,13 +436,13 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     step(5);
     for (int l = P.a.L_ - 1; l >= 0; --l) { if (l > 0) dx(0, l, 0); dw(0, l); }
     WIDE_CHECK();
-    return ddpg_apply_launch(Pp, 0, st);
+    return finish(0);
   }
   // critic: y = r + gamma Q'(s', pi'(s')), then learn_batch (DeepQNAg.hpp:379-408)
   step(0); fwd(0, 1); step(1); fwd(1, 1); step(2); fwd(1, 0); step(3);
   for (int l = P.q.L_ - 1; l >= 0; --l) { if (l > 0) dx(1, l, 0); dw(1, l); }
   WIDE_CHECK();
-  if ((e = ddpg_apply_launch(Pp, 1, st)) != hipSuccess) return e;
+  if ((e = finish(1)) != hipSuccess) return e;
   // actor: dQ/da through the NEW critic, inverting gradients, actor backward (:411-459)
   fwd(0, 0); step(1); fwd(1, 0); step(4);
   for (int l = P.q.L_ - 1; l >= 1; --l) dx(1, l, 0);
@@ -410,7 +450,7 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
   step(5);
   for (int l = P.a.L_ - 1; l >= 0; --l) { if (l > 0) dx(0, l, 0); dw(0, l); }
   WIDE_CHECK();
-  return ddpg_apply_launch(Pp, 0, st);
+  return finish(0);
 }
 
 extern "C" hipError_t ddpg_update_wide_launch(const DdpgParams *P, hipStream_t st) { return wide_launch(P, 0, 0, st); }

@@ -316,6 +316,9 @@ def test_large_minibatch_updates(ora, B, hidden_a, hidden_q, kw):
     (96, (160, 200), (300,), dict(nstep_return=2, goal_prob=0.1, momentum=1, decay_v=1e-3)),
     (64, (100, 100), (100, 100), dict(force_wide=True)),
     (32, (20,), (50, 7), dict(force_wide=True, inverting_grad=False)),
+    # EWC on both nets, Fisher accumulating: one chunk (the optimiser runs inside the dW kernels) and two (partials + apply)
+    (64, (160, 130), (140, 129), dict(ewc=100.0, ewc_fisher_beta=0.999, ewc_for_critic=1)),
+    (100, (160, 130), (140, 129), dict(ewc=100.0, ewc_fisher_beta=0.999, ewc_for_critic=1)),
 ])
 def test_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, kw):
     G = 2
@@ -336,6 +339,13 @@ def test_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, kw):
             assert e <= TOL or close_frac(last["dact"][g], dact, TOL, frac=0.99), e
         check_step(pop, agents, ws_prev, _hyper(agents), kw.get("momentum", 0), TOL, allow_kink=True)
     assert list(pop.adam(0)[2]) == [3, 3]
+    if kw.get("ewc", -1.0) >= 0:              # the running Fisher of three updates (the oracle's gradients were resynced each step)
+        for net in (0, 1):
+            st = pop.ewc_state(net)
+            for g, ag in enumerate(agents):
+                so = ag.nets[net].ewc_state()
+                assert close_frac(st["fisher"][g], so["fisher"], 1e-4, 0.99, 1e-1), (net, g)
+                assert abs(st["fisher_nbr"][g] - so["fisher_nbr"]) <= 1e-5 * so["fisher_nbr"]
     # inference through the wide nets
     s = rng.uniform(-1, 1, (G, 18)).astype(np.float32)
     a = pop.infer(s)
