@@ -7,9 +7,11 @@ import ddrl_amd
 from bench import synth_rows, algorithmic_work
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ewc = len(sys.argv) < 3 or sys.argv[2] == "ewc"
-S, A, B = 18, 6, 64
-cfg = ddrl_amd.DdpgConfig(n_agents=G, replay_memory=2000, inverting_grad=0, td3=1, policy_freq=2,
-                          ewc=100.0 if ewc else -1.0, ewc_for_critic=1)
+hidden = tuple(int(x) for x in sys.argv[3].split("x")) if len(sys.argv) > 3 else (100, 100)     # e.g. 400x300
+S, A = 18, 6
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+cfg = ddrl_amd.DdpgConfig(n_agents=G, replay_memory=2000, inverting_grad=0, td3=1, policy_freq=2, mini_batch_size=B,
+                          hidden_unit_a=hidden, hidden_unit_q=hidden, ewc=100.0 if ewc else -1.0, ewc_for_critic=1)
 pop = ddrl_amd.Td3Population(cfg, init_seed=1)
 rows = synth_rows(0, 2000, S, A)
 for g in range(G):
@@ -17,7 +19,8 @@ for g in range(G):
 pop.update()
 if ewc:
     pop.update_best_param(np.ones(G)); pop.ewc_setup()
-byts, flops, Na, Nc = algorithmic_work(S, A, B, (100, 100), (100, 100), ewc)
+byts, flops, Na, Nc = algorithmic_work(S, A, B, hidden, hidden, ewc)
+print("TD3, %d agents, nets %s, B=%d, EWC %s" % (G, "x".join(map(str, hidden)), B, "on" if ewc else "off"))
 per = 36 + (16 if ewc else 0)
 for name, astep, nbytes in (("policy step", 1, per * (Na + 2 * Nc)), ("critic-only step", 0, per * 2 * Nc), ("alternating (policy_freq=2)", None, per * (Na / 2 + 2 * Nc))):
     for _ in range(4):
