@@ -3,9 +3,9 @@
 // the same order of operations as the fused kernel (kernels_ddpg.hip, DeepQNAg.hpp:343-466), but one
 // launch per layer operation: the 64-row activation tiles of an (agent, chunk) live in an HBM scratch
 // block (L2 resident between launches) instead of LDS, every launch spreads an agent's layer over
-// several workgroups (64-column blocks), and parameter gradients go through the per-chunk partials
-// and apply kernels of kernels_ddpg_big.hip.  Weights keep the tile-major layout, so weight
-// fragments are still contiguous 1-KiB wave loads.
+// several workgroups (64-column blocks), and a layer's dW kernel sums the minibatch's chunks in its
+// MFMA accumulators and runs the optimiser epilogue itself (no per-chunk partials, no apply launch).
+// Weights keep the tile-major layout, so weight fragments are still contiguous 1-KiB wave loads.
 #include "ddpg_device.h"
 
 struct WideMap {
@@ -205,28 +205,23 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
   }
 }
 
-// dW[64 n-block x all k] = dZ^T X over the chunk's 64 rows (+ db), written to the chunk's partial-gradient
-// image (same layout as the weights).  One workgroup per 64-column block of dZ: the block is staged in LDS
-// once and the 64-column blocks of X stream past it.
-// FUSE (one-chunk minibatches: the chunk's gradient IS the minibatch gradient): every tile goes from the MFMA
-// accumulator straight through the optimiser epilogue of the fused kernel (opt_load4 / opt_step4: Fisher EMA,
-// EWC penalty, L2, Adam, soft target update) -- no partial-gradient image, no apply launch; the tile's state
-// is requested before its products.  The layer's input-gradient kernel has run before (old weights).
-template <bool FUSE, bool EWC>
+// dW[64 n-block x all k] = sum over the minibatch's 64-row chunks of dZ^T X (+ db), every tile handed from the
+// MFMA accumulators straight to the optimiser epilogue of the fused kernel (opt_load4 / opt_step4: Fisher EMA,
+// EWC penalty, L2, Adam, soft target update): no partial-gradient image, no apply launch.  One workgroup per
+// 64-column block of dZ; for every 64-column block of X the chunks' tiles of dZ and X are staged in LDS in turn
+// (one chunk: the block of dZ is staged once and the blocks of X stream past it).  The layer's input-gradient
+// kernel has run before (old weights), and the activations are still intact (wide_dz).
+template <bool EWC>
 __global__ void __launch_bounds__(256)
 wide_dw_kernel(const DdpgParams P, const WideOp op) {
   __shared__ __align__(16) float sY[DDRL_MB * 68], sX[DDRL_MB * 68];
-  const int nb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
-  if (wide_skip(P, agent, chunk, op.policy)) return;
+  const int nb = blockIdx.x, agent = blockIdx.z;
+  if (wide_skip(P, agent, 0, op.policy)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
   const NetDesc &nd = op.net ? P.q : P.a;
   const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
-  const int KB = (kp + 63) >> 6;
-  const WideMap W = wide_map(P, agent, chunk);
-  float *X, *dZ; int ldx, ldz;
-  wide_io(P, W, op.net, l, nd, X, ldx, dZ, ldz);
-  dZ = wide_dz(W, op.net, l, nd);
-  // 16-byte pieces: row strides and block offsets are multiples of 4 floats; columns [N, ldz) / [kp, ldx) hold zeros
+  const int KB = (kp + 63) >> 6, NCH = (P.B + DDRL_MB - 1) / DDRL_MB;
+  // 16-byte pieces: row strides and block offsets are multiples of 4 floats
   auto stage = [&](float *dst, const float *src, int ld, int col0, int width) {
     for (int e = tid; e < DDRL_MB * 16; e += 256) {
       const int row = e >> 4, c4 = (e & 15) * 4;
@@ -237,39 +232,43 @@ wide_dw_kernel(const DdpgParams P, const WideOp op) {
       *(f32x4 *)(dst + row * 68 + c4) = v;
     }
   };
-  stage(sY, dZ, ldz, nb * 64, N);
   const int Nloc = N - nb * 64 < 64 ? N - nb * 64 : 64;
-  float *gout = FUSE ? nullptr : (op.net == 2 ? P.gpart_q2 : op.net ? P.gpart_q : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
-  OptCtx o = {};
-  if (FUSE) {
-    // TD3 (the only caller that sets actor_step): the critics' targets move on a policy step only (tau = 0 in between)
-    const bool pstep = P.actor_step ? P.actor_step[agent] != 0 : true;
-    const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
-    o = make_opt<EWC>(P, st, nd.stride(), agent, pstep ? P.tau[agent] : 0.f, pstep ? P.omtau[agent] : 1.f, (float)P.B);
-  }
+  // TD3 (the only caller that sets actor_step): the critics' targets move on a policy step only (tau = 0 in between)
+  const bool pstep = P.actor_step ? P.actor_step[agent] != 0 : true;
+  const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
+  const OptCtx o = make_opt<EWC>(P, st, nd.stride(), agent, pstep ? P.tau[agent] : 0.f, pstep ? P.omtau[agent] : 1.f, (float)P.B);
+  float db = 0.f;
   for (int kb = 0; kb < KB; ++kb) {
-    if (kb) __syncthreads();               // every wave is done with the previous block of X
-    stage(sX, X, ldx, kb * 64, kp);
-    __syncthreads();
     const int kploc = kp - kb * 64 < 64 ? kp - kb * 64 : 64;
-#pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
+    auto elem = [&](int t, bool &ok) {     // lane's four parameters of tile t of this (n, k) block
       const int p = wave * 4 + t;
       const int n = nb * 64 + (p >> 2) * 16 + c, k = kb * 64 + (p & 3) * 16 + 4 * g;
-      const bool ok = n < N && k < kp;
-      const int i = ok ? nd.offw(l) + ddrl_widx(n, k, kp) : nd.offw(l);      // (clamped: the state loaded there is ignored)
+      ok = n < N && k < kp;
+      return ok ? nd.offw(l) + ddrl_widx(n, k, kp) : nd.offw(l);      // (clamped: the state loaded there is ignored)
+    };
+    f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+    for (int ch = 0; ch < NCH; ++ch) {
+      const WideMap W = wide_map(P, agent, ch);
+      float *X, *dZ; int ldx, ldz;
+      wide_io(P, W, op.net, l, nd, X, ldx, dZ, ldz);
+      if (kb || ch) __syncthreads();         // every wave is done with the previous tiles
+      if (NCH > 1 || kb == 0) stage(sY, wide_dz(W, op.net, l, nd), ldz, nb * 64, N);   // one chunk: staged once
+      stage(sX, X, ldx, kb * 64, kp);
+      __syncthreads();
+      if (kb == 0 && tid < 64) db += bias_grad(sY, 68, tid);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] += dw_tile(sY, 68, Nloc, sX, 68, kploc, wave * 4 + t, 16, 4, c, g);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {          // (requesting the state before the products measured no faster)
+      bool ok;
+      const int i = elem(t, ok);
       OptRegs r;
-      if (FUSE) opt_load4<EWC, true>(o, i, r);
-      const f32x4 acc = dw_tile(sY, 68, Nloc, sX, 68, kploc, p, 16, 4, c, g);
-      if (FUSE) opt_step4<EWC, true>(o, i, acc, r, ok);
-      else if (ok) *(f32x4 *)(gout + i) = acc;
+      opt_load4<EWC, true>(o, i, r);
+      opt_step4<EWC, true>(o, i, acc[t], r, ok);
     }
   }
-  if (tid < 64 && nb * 64 + tid < N) {
-    const float db = bias_grad(sY, 68, tid);
-    if (FUSE) opt_step<EWC, true>(o, nd.offb(l) + nb * 64 + tid, db);
-    else gout[nd.offb(l) + nb * 64 + tid] = db;
-  }
+  if (tid < 64 && nb * 64 + tid < N) opt_step<EWC, true>(o, nd.offb(l) + nb * 64 + tid, db);
 }
 
 // the element-wise steps between the layer launches, one workgroup per (chunk, agent)
@@ -320,13 +319,17 @@ wide_step_kernel(const DdpgParams P, int step, int policy) {
     }
   } else if (step == 4) {                // DPG seed (:424-428), NOT / B
     if (tid < DDRL_MB) M.topq[tid * ldq] = tid < nrows ? -1.0f : 0.f;
-  } else if (step >= 10 && step <= 12) { // one-chunk minibatches (optimiser fused into the dW kernels): Solver::iter, Fisher count, loss
+  } else if (step >= 10 && step <= 12) { // the bookkeeping of a net's update (the optimiser itself runs inside the dW kernels)
     const int net = step - 10;
     const NetState &st = net == 2 ? P.sq2 : net ? P.sq : P.sa;
     if (chunk == 0 && tid == 0) {
       st.iter[agent] += 1;
       if (st.fisher) st.fisher_nbr[agent] = st.fisher_nbr[agent] * P.fisher_beta + (float)B;
-      if (net >= 1) (net == 1 ? P.loss_out : P.loss2_out)[agent] = (net == 1 ? P.loss_part : P.loss_part2)[(size_t)agent * P.maxchunks] / (float)B * 0.5f;
+      if (net >= 1) {
+        float sum = 0.f;
+        for (int ch = 0; ch * DDRL_MB < B; ++ch) sum += (net == 1 ? P.loss_part : P.loss_part2)[(size_t)agent * P.maxchunks + ch];
+        (net == 1 ? P.loss_out : P.loss2_out)[agent] = sum / (float)B * 0.5f;
+      }
     }
   } else if (step == 6) {                // TD3: a' = clip(a' + eps, -1, 1) between the two gates (TD3Ag.hpp:307-309)
     const float *noise = P.noise + ((size_t)agent * B + row0) * A;
@@ -378,7 +381,6 @@ wide_step_kernel(const DdpgParams P, int step, int policy) {
 }
 
 extern "C" size_t ddpg_wide_block_floats(const DdpgParams *P) { return wide_block_floats(*P); }
-extern "C" hipError_t ddpg_apply_launch(const DdpgParams *P, int net, hipStream_t st);
 
 #define WIDE_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -402,19 +404,16 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     const WideOp op = {net, 0, l, mode, policy};
     hipLaunchKernelGGL(wide_dx_kernel, dim3((nd.kp_[l] + 63) / 64, C, G), dim3(256), 0, st, P, op);
   };
-  const bool fuse = C == 1;               // one chunk: the optimiser runs inside the dW kernels, no apply launch
-  auto dw = [&](int net, int l) {
+  auto dw = [&](int net, int l) {          // all chunks of the minibatch in one workgroup: grid.y = 1
     const NetDesc &nd = net ? P.q : P.a;
     const WideOp op = {net, 0, l, 0, policy};
-    const dim3 grid((nd.d_[l + 1] + 63) / 64, C, G);
+    const dim3 grid((nd.d_[l + 1] + 63) / 64, 1, G);
     const bool ewc = (net == 2 ? P.sq2 : net ? P.sq : P.sa).fisher != nullptr;
-    if (!fuse) hipLaunchKernelGGL((wide_dw_kernel<false, false>), grid, dim3(256), 0, st, P, op);
-    else if (ewc) hipLaunchKernelGGL((wide_dw_kernel<true, true>), grid, dim3(256), 0, st, P, op);
-    else hipLaunchKernelGGL((wide_dw_kernel<true, false>), grid, dim3(256), 0, st, P, op);
+    if (ewc) hipLaunchKernelGGL((wide_dw_kernel<true>), grid, dim3(256), 0, st, P, op);
+    else hipLaunchKernelGGL((wide_dw_kernel<false>), grid, dim3(256), 0, st, P, op);
   };
-  // after a net's backward pass: the apply kernel over the chunk partials, or the fused path's bookkeeping
+  // after a net's backward pass: Solver::iter, the Fisher count, the loss (the optimiser ran inside the dW kernels)
   auto finish = [&](int net) -> hipError_t {
-    if (!fuse) return ddpg_apply_launch(Pp, net, st);
     step(10 + net);
     return hipGetLastError();
   };
