@@ -218,7 +218,7 @@ def main():
                    "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "kernel": "ddpg_update_kernel" if max(ha + hq) <= 128 else "wide_* layer kernels + ddpg_apply_kernel (one update = 45 launches)",
+                     "kernel": "ddpg_update_kernel" if max(ha + hq) <= 128 else "wide_* layer kernels, optimiser inside the dW kernels (one update = 45 launches)",
                      "kernel_avg_ms": kavg * 1e3, "launches": launches,
                      "updates_per_launch": upl_eff, "algorithmic_bytes_per_launch": byts * G * upl_eff,
                      "algorithmic_bytes_per_agent_update": byts,
