@@ -71,15 +71,29 @@ __device__ __forceinline__ float *wide_dz(const WideMap &W, int net, int l, cons
   return l == nd.L() - 1 ? (net ? W.M.topq : W.M.topa) : W.dz + l * W.hstride;
 }
 
+// XCD-aware workgroup order of the forward / input-gradient launches.  Workgroups go to the 8 XCDs round-robin by
+// linear id, and the NB column blocks of one (agent, chunk) read the same 64 activation rows: they take
+// consecutive slots of ONE XCD, so the rows come from HBM once and from that XCD's L2 afterwards (with x = column
+// block, the blocks of a pair sat on NB different XCDs and each fetched the rows again: as many bytes as the weights).
+__host__ __device__ inline unsigned wide_grid(int NB, int C, int G) { return (unsigned)((C * G + 7) / 8 * 8) * NB; }
+__device__ __forceinline__ bool wide_decode(int NB, int C, int G, int &nb, int &chunk, int &agent) {
+  const unsigned id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  nb = j % NB;
+  const unsigned pair = (j / NB) * 8 + xcd;
+  chunk = pair % C; agent = pair / C;
+  return agent < G;
+}
+
 // Y[64 x N] = act(X W^T + b): one 64-column block of outputs per workgroup, wave w owns rows 16w..16w+15
 __global__ void __launch_bounds__(256)
 wide_fwd_kernel(const DdpgParams P, const WideOp op) {
-  const int nb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
+  const NetDesc &nd = op.net ? P.q : P.a;
+  const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
+  int nb, chunk, agent;
+  if (!wide_decode((nd.ld(l + 1) + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, nb, chunk, agent)) return;
   if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  const NetDesc &nd = op.net ? P.q : P.a;
   const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
-  const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
   const float *wn = (op.target ? st.wt : st.w) + (size_t)agent * nd.stride();
   const float *Wl = wn + nd.offw(l), *bias = wn + nd.offb(l);
   const WideMap W = wide_map(P, agent, chunk);
@@ -106,12 +120,13 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
     const float *blk = Wl + ddrl_tile_base(nt, kcc, kp) + c * kw;
     return *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
   };
-  f32x4 a_cur = load_a(0), b_nxt = load_b(0), a_nxt;
+  f32x4 a_cur = load_a(0), b_nxt = load_b(0), a_nxt = load_a(1), a_far, b_far;
   *(f32x4 *)&sB[0][wave][lane * 4] = b_nxt;
+  b_nxt = load_b(1);
   for (int kc = 0; kc < KC; ++kc) {
     const int cur = kc & 1;
-    a_nxt = load_a(kc + 1);
-    b_nxt = load_b(kc + 1);
+    a_far = load_a(kc + 2);                // two chunks in flight: the loads come from HBM (every agent has its own weights)
+    b_far = load_b(kc + 2);
     __syncthreads();                       // sB[cur] is complete; nobody reads sB[cur ^ 1] any more
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -120,7 +135,7 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
       for (int e = 0; e < 4; ++e) acc[t] = mfma16(a_cur[e], b[e], acc[t]);
     }
     *(f32x4 *)&sB[cur ^ 1][wave][lane * 4] = b_nxt;
-    a_cur = a_nxt;
+    a_cur = a_nxt; a_nxt = a_far; b_nxt = b_far;
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -139,12 +154,13 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
 // mode 1 (layer 0 of the critic): the action columns [S, S + A) go to W.da untouched.
 __global__ void __launch_bounds__(256)
 wide_dx_kernel(const DdpgParams P, const WideOp op) {
-  const int kb = blockIdx.x, chunk = blockIdx.y, agent = blockIdx.z;
+  const NetDesc &nd = op.net ? P.q : P.a;
+  const int l = op.l, kp = nd.kp(l), K = nd.d(l), N = nd.d(l + 1);
+  int kb, chunk, agent;
+  if (!wide_decode((kp + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, kb, chunk, agent)) return;
   if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  const NetDesc &nd = op.net ? P.q : P.a;
   const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
-  const int l = op.l, kp = nd.kp(l), K = nd.d(l), N = nd.d(l + 1);
   const float *Wl = st.w + (size_t)agent * nd.stride() + nd.offw(l);
   const WideMap W = wide_map(P, agent, chunk);
   float *in, *dZ; int ldi, ldz;
@@ -173,12 +189,13 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
     for (int j = 0; j < 4; ++j) b[j] = blk[j * kw];
     return b;
   };
-  f32x4 a_cur = load_a(0), b_nxt = load_b(0), a_nxt;
+  f32x4 a_cur = load_a(0), b_nxt = load_b(0), a_nxt = load_a(1), a_far, b_far;
   *(f32x4 *)&sB[0][wave][lane * 4] = b_nxt;
+  b_nxt = load_b(1);
   for (int nc = 0; nc < NC; ++nc) {
     const int cur = nc & 1;
-    a_nxt = load_a(nc + 1);
-    b_nxt = load_b(nc + 1);
+    a_far = load_a(nc + 2);
+    b_far = load_b(nc + 2);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -187,7 +204,7 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
       for (int j = 0; j < 4; ++j) acc[t] = mfma16(a_cur[j], b[j], acc[t]);
     }
     *(f32x4 *)&sB[cur ^ 1][wave][lane * 4] = b_nxt;
-    a_cur = a_nxt;
+    a_cur = a_nxt; a_nxt = a_far; b_nxt = b_far;
   }
   const int S = P.S, A = P.A, ldda = ddrl_ldpad(A);
 #pragma unroll
@@ -396,13 +413,13 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     const NetDesc &nd = net ? P.q : P.a;
     for (int l = 0; l < nd.L_; ++l) {
       const WideOp op = {net, target, l, 0, policy};
-      hipLaunchKernelGGL(wide_fwd_kernel, dim3((nd.ld_[l + 1] + 63) / 64, C, G), dim3(256), 0, st, P, op);
+      hipLaunchKernelGGL(wide_fwd_kernel, dim3(wide_grid((nd.ld_[l + 1] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
     }
   };
   auto dx = [&](int net, int l, int mode) {
     const NetDesc &nd = net ? P.q : P.a;
     const WideOp op = {net, 0, l, mode, policy};
-    hipLaunchKernelGGL(wide_dx_kernel, dim3((nd.kp_[l] + 63) / 64, C, G), dim3(256), 0, st, P, op);
+    hipLaunchKernelGGL(wide_dx_kernel, dim3(wide_grid((nd.kp_[l] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
   };
   auto dw = [&](int net, int l) {          // all chunks of the minibatch in one workgroup: grid.y = 1
     const NetDesc &nd = net ? P.q : P.a;
