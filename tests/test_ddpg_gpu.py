@@ -316,7 +316,7 @@ def test_large_minibatch_updates(ora, B, hidden_a, hidden_q, kw):
     (96, (160, 200), (300,), dict(nstep_return=2, goal_prob=0.1, momentum=1, decay_v=1e-3)),
     (64, (100, 100), (100, 100), dict(force_wide=True)),
     (32, (20,), (50, 7), dict(force_wide=True, inverting_grad=False)),
-    # EWC on both nets, Fisher accumulating: one chunk (the optimiser runs inside the dW kernels) and two (partials + apply)
+    # EWC on both nets, Fisher accumulating: one chunk and two (the dW kernels sum the chunks and run the optimiser)
     (64, (160, 130), (140, 129), dict(ewc=100.0, ewc_fisher_beta=0.999, ewc_for_critic=1)),
     (100, (160, 130), (140, 129), dict(ewc=100.0, ewc_fisher_beta=0.999, ewc_for_critic=1)),
 ])
@@ -351,6 +351,24 @@ def test_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, kw):
     a = pop.infer(s)
     for g, ag in enumerate(agents):
         assert np.max(np.abs(a[g] - ag.ann.forward(s[g].astype(np.float64))[0])) <= 1e-5
+
+
+@pytest.mark.parametrize("G,B", [(19, 100), (24, 64)])
+def test_wide_nets_many_agents(ora, G, B):
+    """the XCD-aware workgroup order of the forward / input-gradient launches (wide_decode) with more (agent, chunk)
+    pairs than XCDs, a pair count that is not a multiple of 8 (19 x 2 chunks) and one that is: every agent against the oracle"""
+    pop, agents = make_pair(ora, G=G, B=B, hidden_a=(160, 130), hidden_q=(140, 129), wscale=0.05, sweep=True, seed=11)
+    for it in range(2):
+        ws_prev, _ = sync_oracle_from_gpu(pop, agents)
+        pop.update()
+        last = pop.last()
+        for g, ag in enumerate(agents):
+            loss, used = ag.update(None)
+            qt, dact = ag.last()
+            assert np.array_equal(used, last["idx"][g]), (it, g)
+            assert rel_err(last["q_targets"][g], qt) <= TOL, (it, g)
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss), (it, g)
+        check_step(pop, agents, ws_prev, _hyper(agents), 0, TOL, allow_kink=True)
 
 
 @pytest.mark.parametrize("B,hidden,kw", [(64, (100, 100), dict()), (32, (20,), dict(nstep_return=2, goal_prob=0.1)), (96, (24, 16), dict())])
