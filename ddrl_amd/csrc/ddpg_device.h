@@ -136,3 +136,18 @@ __device__ __forceinline__ LdsMap ddpg_carve(float *p, int La, int Lq, int ldh, 
   M.nvalid = (int *)p; p += DDRL_MB;
   return M;
 }
+
+// XCD-aware workgroup order (layer-by-layer forward / input-gradient launches, chunk launches of large minibatches).
+// Workgroups go to the 8 XCDs round-robin by linear id.  The NB column blocks of one (agent, chunk) read the same 64
+// activation rows, the chunks of one agent the same weights: such a group takes consecutive slots of ONE XCD, so
+// the shared operand comes from HBM once and from that XCD's L2 afterwards (with x = block, the group sat on
+// different XCDs and each member fetched it again).  NB blocks per group, C x G groups.
+__host__ __device__ inline unsigned xcd_grid(int NB, int C, int G) { return (unsigned)((C * G + 7) / 8 * 8) * NB; }
+__device__ __forceinline__ bool xcd_decode(int NB, int C, int G, int &nb, int &chunk, int &agent) {
+  const unsigned id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  nb = j % NB;
+  const unsigned pair = (j / NB) * 8 + xcd;
+  chunk = pair % C; agent = pair / C;
+  return agent < G;
+}
+

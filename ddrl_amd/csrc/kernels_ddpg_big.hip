@@ -16,7 +16,8 @@ template <int PHASE, bool TD3>
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 ddpg_chunk_kernel(const DdpgParams P) {
   extern __shared__ __align__(16) float lds[];
-  const int chunk = blockIdx.x, agent = blockIdx.y;
+  int chunk, one, agent;                // an agent's chunks on one XCD: its weights come from that L2 after the first
+  if (!xcd_decode((P.B + DDRL_MB - 1) / DDRL_MB, 1, P.G, chunk, one, agent)) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (P.mask && !P.mask[agent]) return;
@@ -178,7 +179,7 @@ static hipError_t launch_chunks(const DdpgParams *P, hipStream_t st) {
   hipError_t e = ddrl_set_lds(ddpg_chunk_kernel<PHASE, TD3>, lds, configured);
   if (e != hipSuccess) return e;
   const int nch = (P->B + DDRL_MB - 1) / DDRL_MB;
-  hipLaunchKernelGGL((ddpg_chunk_kernel<PHASE, TD3>), dim3(nch, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  hipLaunchKernelGGL((ddpg_chunk_kernel<PHASE, TD3>), dim3(xcd_grid(nch, 1, P->G)), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
 }
 

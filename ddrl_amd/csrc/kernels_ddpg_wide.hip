@@ -71,26 +71,13 @@ __device__ __forceinline__ float *wide_dz(const WideMap &W, int net, int l, cons
   return l == nd.L() - 1 ? (net ? W.M.topq : W.M.topa) : W.dz + l * W.hstride;
 }
 
-// XCD-aware workgroup order of the forward / input-gradient launches.  Workgroups go to the 8 XCDs round-robin by
-// linear id, and the NB column blocks of one (agent, chunk) read the same 64 activation rows: they take
-// consecutive slots of ONE XCD, so the rows come from HBM once and from that XCD's L2 afterwards (with x = column
-// block, the blocks of a pair sat on NB different XCDs and each fetched the rows again: as many bytes as the weights).
-__host__ __device__ inline unsigned wide_grid(int NB, int C, int G) { return (unsigned)((C * G + 7) / 8 * 8) * NB; }
-__device__ __forceinline__ bool wide_decode(int NB, int C, int G, int &nb, int &chunk, int &agent) {
-  const unsigned id = blockIdx.x, xcd = id & 7, j = id >> 3;
-  nb = j % NB;
-  const unsigned pair = (j / NB) * 8 + xcd;
-  chunk = pair % C; agent = pair / C;
-  return agent < G;
-}
-
 // Y[64 x N] = act(X W^T + b): one 64-column block of outputs per workgroup, wave w owns rows 16w..16w+15
 __global__ void __launch_bounds__(256)
 wide_fwd_kernel(const DdpgParams P, const WideOp op) {
   const NetDesc &nd = op.net ? P.q : P.a;
   const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
   int nb, chunk, agent;
-  if (!wide_decode((nd.ld(l + 1) + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, nb, chunk, agent)) return;
+  if (!xcd_decode((nd.ld(l + 1) + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, nb, chunk, agent)) return;
   if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
@@ -157,7 +144,7 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
   const NetDesc &nd = op.net ? P.q : P.a;
   const int l = op.l, kp = nd.kp(l), K = nd.d(l), N = nd.d(l + 1);
   int kb, chunk, agent;
-  if (!wide_decode((kp + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, kb, chunk, agent)) return;
+  if (!xcd_decode((kp + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, kb, chunk, agent)) return;
   if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
@@ -413,13 +400,13 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     const NetDesc &nd = net ? P.q : P.a;
     for (int l = 0; l < nd.L_; ++l) {
       const WideOp op = {net, target, l, 0, policy};
-      hipLaunchKernelGGL(wide_fwd_kernel, dim3(wide_grid((nd.ld_[l + 1] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
+      hipLaunchKernelGGL(wide_fwd_kernel, dim3(xcd_grid((nd.ld_[l + 1] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
     }
   };
   auto dx = [&](int net, int l, int mode) {
     const NetDesc &nd = net ? P.q : P.a;
     const WideOp op = {net, 0, l, mode, policy};
-    hipLaunchKernelGGL(wide_dx_kernel, dim3(wide_grid((nd.kp_[l] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
+    hipLaunchKernelGGL(wide_dx_kernel, dim3(xcd_grid((nd.kp_[l] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
   };
   auto dw = [&](int net, int l) {          // all chunks of the minibatch in one workgroup: grid.y = 1
     const NetDesc &nd = net ? P.q : P.a;

@@ -353,11 +353,13 @@ def test_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, kw):
         assert np.max(np.abs(a[g] - ag.ann.forward(s[g].astype(np.float64))[0])) <= 1e-5
 
 
-@pytest.mark.parametrize("G,B", [(19, 100), (24, 64)])
-def test_wide_nets_many_agents(ora, G, B):
-    """the XCD-aware workgroup order of the forward / input-gradient launches (wide_decode) with more (agent, chunk)
-    pairs than XCDs, a pair count that is not a multiple of 8 (19 x 2 chunks) and one that is: every agent against the oracle"""
-    pop, agents = make_pair(ora, G=G, B=B, hidden_a=(160, 130), hidden_q=(140, 129), wscale=0.05, sweep=True, seed=11)
+@pytest.mark.parametrize("G,B,hidden_a,hidden_q", [(19, 100, (160, 130), (140, 129)), (24, 64, (160, 130), (140, 129)),
+                                                   (11, 160, (32, 16), (24, 16))])
+def test_xcd_order_many_agents(ora, G, B, hidden_a, hidden_q):
+    """the XCD-aware workgroup order (xcd_decode) of the layer-by-layer forward / input-gradient launches and of the
+    chunk launches of large minibatches (third case) with more groups than XCDs, counts that are not a multiple
+    of 8 (19 x 2 chunks, 11 agents) and one that is: every agent against the oracle"""
+    pop, agents = make_pair(ora, G=G, B=B, hidden_a=hidden_a, hidden_q=hidden_q, wscale=0.05 if max(hidden_a) > 128 else 0.1, sweep=True, seed=11)
     for it in range(2):
         ws_prev, _ = sync_oracle_from_gpu(pop, agents)
         pop.update()
