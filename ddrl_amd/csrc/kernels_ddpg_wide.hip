@@ -93,11 +93,11 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
   // The four waves need the same weight fragments (they differ in their batch rows only): wave w fetches tile w
   // of the k-chunk once and hands it to the others through LDS, double-buffered, one barrier per k-chunk;
   // chunk kc + 1 travels (global -> registers) while chunk kc is multiplied.
-  __shared__ __align__(16) float sB[2][4][256];
-  auto load_a = [&](int kc) {
+  __shared__ __align__(16) float sB[2][2][4][256];     // two k-chunks per barrier
+  auto load_a = [&](int kc) {              // chunks beyond the layer multiply as zeros
     const int kcc = kc < KC ? kc : KC - 1;
-    const bool in = kcc * 16 + 4 * g < kp;
-    f32x4 a = *(const f32x4 *)(xrow + (in ? kcc * 16 + 4 * g : kp - 4));
+    const bool in = kc < KC && kcc * 16 + 4 * g < kp;
+    f32x4 a = *(const f32x4 *)(xrow + (kcc * 16 + 4 * g < kp ? kcc * 16 + 4 * g : kp - 4));
     return in ? a : zero4();
   };
   auto load_b = [&](int kc) {              // this wave's tile (t = wave) of chunk kc
@@ -107,22 +107,25 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
     const float *blk = Wl + ddrl_tile_base(nt, kcc, kp) + c * kw;
     return *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));
   };
-  f32x4 a_cur = load_a(0), b_nxt = load_b(0), a_nxt = load_a(1), a_far, b_far;
-  *(f32x4 *)&sB[0][wave][lane * 4] = b_nxt;
-  b_nxt = load_b(1);
-  for (int kc = 0; kc < KC; ++kc) {
-    const int cur = kc & 1;
-    a_far = load_a(kc + 2);                // two chunks in flight: the loads come from HBM (every agent has its own weights)
-    b_far = load_b(kc + 2);
+  f32x4 a_cur[2] = {load_a(0), load_a(1)}, b_nxt[2] = {load_b(0), load_b(1)}, a_nxt[2];
+  *(f32x4 *)&sB[0][0][wave][lane * 4] = b_nxt[0];
+  *(f32x4 *)&sB[0][1][wave][lane * 4] = b_nxt[1];
+  for (int kc = 0, it = 0; kc < KC; kc += 2, ++it) {
+    const int cur = it & 1;
+    a_nxt[0] = load_a(kc + 2); a_nxt[1] = load_a(kc + 3);
+    b_nxt[0] = load_b(kc + 2); b_nxt[1] = load_b(kc + 3);
     __syncthreads();                       // sB[cur] is complete; nobody reads sB[cur ^ 1] any more
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 b = *(const f32x4 *)&sB[cur][t][lane * 4];
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[t] = mfma16(a_cur[e], b[e], acc[t]);
-    }
-    *(f32x4 *)&sB[cur ^ 1][wave][lane * 4] = b_nxt;
-    a_cur = a_nxt; a_nxt = a_far; b_nxt = b_far;
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 b = *(const f32x4 *)&sB[cur][h][t][lane * 4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t] = mfma16(a_cur[h][e], b[e], acc[t]);
+      }
+    *(f32x4 *)&sB[cur ^ 1][0][wave][lane * 4] = b_nxt[0];
+    *(f32x4 *)&sB[cur ^ 1][1][wave][lane * 4] = b_nxt[1];
+    a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
