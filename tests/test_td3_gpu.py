@@ -166,6 +166,15 @@ def test_td3_wide_nets_layer_by_layer(ora, B, hidden_a, hidden_q, forced):
         step_and_check(pop, agents, idx, noise, astep)
 
 
+@pytest.mark.parametrize("G,B,hidden_a,hidden_q", [(13, 100, (160, 96), (144, 130)), (11, 160, (32, 16), (24, 16))])
+def test_td3_xcd_order_many_agents(ora, G, B, hidden_a, hidden_q):
+    """more workgroup groups than XCDs (xcd_decode: layer-by-layer launches, chunk launches), agents on and off a
+    policy step interleaved: every agent against the oracle"""
+    pop, agents = make_td3(ora, G=G, B=B, hidden_a=hidden_a, hidden_q=hidden_q, seed=12, wscale=0.05 if max(hidden_a) > 128 else 0.1)
+    for astep in ((np.arange(G) % 3 != 1).astype(int).tolist(), None):
+        step_and_check(pop, agents, None, None, astep)
+
+
 def test_td3_free_indices_and_device_noise(ora):
     """device-drawn indices (bit-exact with the oracle's mt19937) and device-drawn smoothing noise,
     six updates with the policy step every second one"""
