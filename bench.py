@@ -12,10 +12,20 @@ resident in HBM when the timed region starts.  Agents are independent: ranks sha
 max-over-ranks only.
 
   python bench.py --gpus N --steps K --warmup W
+
+N > 1: when the process was not started by torch.distributed.run (no RANK / WORLD_SIZE in the environment),
+this process only LAUNCHES: it starts N fresh children, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set), before anything here has touched the GPU, relays rank 0's JSON line and
+exits with the worst child status.  At N > 1 the line carries both sweeps: `value` is the weak-scaling one
+(--agents per GPU, default 1024), `strong` the metric's own configuration (1024 agents in total = 1024 / N per GPU).
+--dry-run: the launcher / rendezvous / clock reduction without GPU or library (gloo; tests/test_bench_launcher_cpu.py).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -57,7 +67,7 @@ def synth_rows(agent, n, S, A):
     return np.concatenate([s, a, s2, r, goal], axis=1).astype(np.float32)
 
 
-def cpu_baseline(S, A, B, ha, hq, ewc, seconds, threads):
+def cpu_baseline(S, A, B, ha, hq, ewc, seconds, threads, replay):
     """The fp64 CPU oracle (oracle/ddpg_ref.c: a restatement standing in for the unavailable Caffe
     CPU path, kind "port"), one independent agent per thread (ctypes releases the GIL), timed on
     this box's host cores for a bounded sample of the same workload."""
@@ -65,14 +75,12 @@ def cpu_baseline(S, A, B, ha, hq, ewc, seconds, threads):
     ora.lib()
     agents = []
     for t in range(threads):
-        ag = ora.Ddpg(S, A, B, ha, hq, replay_cap=2000, ewc=100.0 if ewc else -1.0, ewc_decay=-1.0,
+        ag = ora.Ddpg(S, A, B, ha, hq, replay_cap=replay, ewc=100.0 if ewc else -1.0, ewc_decay=-1.0,
                       ewc_for_critic=1, seed=3000 + t)
         rng = np.random.RandomState(2000 + t)
-        for n in ag.nets:
-            pass
         wa = rng.normal(0, 0.01, ag.ann.np); wq = rng.normal(0, 0.01, ag.qnn.np)
         ag.ann.set_weights(wa); ag.ann_target.set_weights(wa); ag.qnn.set_weights(wq); ag.qnn_target.set_weights(wq)
-        rows = synth_rows(t, 2000, S, A).astype(np.float64)
+        rows = synth_rows(t, replay, S, A).astype(np.float64)
         for row in rows:
             ag.insert(row[:S], row[S:S + A], row[2 * S + A], row[S + A:2 * S + A], row[2 * S + A + 1] != 0)
         if ewc:
@@ -94,61 +102,88 @@ def cpu_baseline(S, A, B, ha, hq, ewc, seconds, threads):
     return sum(counts) / dt, sum(counts), dt
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--agents", type=int, default=1024, help="agents per GPU")
-    ap.add_argument("--size", default="mid", choices=sorted(SIZES))
-    ap.add_argument("--no-ewc", action="store_true")
-    ap.add_argument("--replay", type=int, default=10000)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--updates-per-launch", type=int, default=8,
-                    help="consecutive updates per agent fused into one launch (ddrl_pop_ddpg_update_n): the reference's "
-                         "fupd loop, 1 + force_more_update = 8 in its ddpg.ini; bit-identical to separate launches")
-    args = ap.parse_args()
+KERNEL_SOURCES = ("kernels_ddpg.hip", "ddpg_device.h", "net_device.h", "mlp_device.h", "pop_internal.h")
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    S, A, B = 18, 6, 64
-    ha, hq = SIZES[args.size]
-    ewc = not args.no_ewc
-    G = args.agents
 
-    # CPU baseline first: before anything initialises the GPU in this process
-    cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu:
-        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-        ups, n, dt = cpu_baseline(S, A, B, ha, hq, ewc, args.cpu_seconds, threads)
-        cpu = {"value": ups, "unit": "updates/s", "cores": threads, "kind": "port",
-               "sample": "%d updates of the same per-agent workload (%s nets, B=64, EWC %s) by the fp64 oracle, "
-                         "one agent per thread, %.1f s" % (n, args.size, "on" if ewc else "off", dt)}
+def kernel_hash():
+    """identifies the update kernel's sources: ties a PMC traffic figure to the build it was measured on"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        p = os.path.join(ROOT, "ddrl_amd", "csrc", f)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
-    import torch
-    import torch.distributed as dist
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+def canned_traffic(G, size, upl_eff):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic_latest.json; bench.py cannot collect
+    PMC counters itself).  Only reported when that file was measured on the kernel sources of this tree."""
+    tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(tp):
+        return None, "not measured"
+    try:
+        tj = json.load(open(tp))
+    except Exception:
+        return None, "profiles/traffic_latest.json unreadable"
+    if tj.get("kernel_hash") != kernel_hash():
+        return None, "stale: profiles/traffic_latest.json was measured on other kernel sources (%s)" % tj.get("kernel_hash", "unhashed, round 1")
+    per_update = {n: tj.get("bytes_per_launch_%d_%s_upl%d" % (G, size, n)) for n in (1, 8)}
+    per_update = {n: v / n for n, v in per_update.items() if v}
+    if not per_update:
+        return None, "no PMC pass for this workload"
+    near = min(per_update, key=lambda n: abs(n - upl_eff))
+    return per_update[near] * upl_eff, "canned: %s" % tj.get("source", "profiles/traffic_latest.json")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed.run: this process never touches the GPU; it starts N
+    fresh interpreters, one per GPU, and relays rank 0's line.  (The other way round -- re-executing a process
+    that has initialised HIP -- is what must never happen.)"""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, DDRL_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % ", ".join("rank %d exit %d" % rc for rc in bad))
+        sys.exit(1)
+
+
+def build_population(G, rank, first_agent, S, A, B, ha, hq, ewc, replay, local_rank):
     import ddrl_amd
-    cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=B, replay_memory=args.replay,
+    cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=B, replay_memory=replay,
                               hidden_unit_a=ha, hidden_unit_q=hq, inverting_grad=1,
                               ewc=100.0 if ewc else -1.0, ewc_decay=-1.0, ewc_fisher_beta=0.999,
                               ewc_for_critic=1, ewc_best_param_method=0, device=local_rank)
     pop = ddrl_amd.DdpgPopulation(cfg, init_seed=2000 + rank)
-    rng = np.random.RandomState(3000 + rank)
-    pop.set_hyper("alpha_a", 10 ** rng.uniform(-5, -2, G)); pop.set_hyper("alpha_v", 10 ** rng.uniform(-5, -2, G))
-    pop.set_hyper("tau_soft_update", 10 ** rng.uniform(-4, -1, G))
-    pop.seed_replay((3000 + rank * G + np.arange(G)).astype(np.uint32))
+    # per-agent hyper-parameters and replay depend on the agent's id in the whole sweep, not on the sharding
+    ids = first_agent + np.arange(G)
+    hyp = np.array([np.random.RandomState(3000 + i).uniform(size=3) for i in ids]).reshape(G, 3)
+    pop.set_hyper("alpha_a", 10 ** (-5 + 3 * hyp[:, 0])); pop.set_hyper("alpha_v", 10 ** (-5 + 3 * hyp[:, 1]))
+    pop.set_hyper("tau_soft_update", 10 ** (-4 + 3 * hyp[:, 2]))
+    pop.seed_replay((3000 + ids).astype(np.uint32))
     for g in range(G):
-        pop.replay_load(g, synth_rows(rank * G + g, args.replay, S, A))
-    upl = max(1, min(args.updates_per_launch, 64))
-    if max(ha + hq) > 128:
-        upl = 1                      # the layer-by-layer path launches per update anyway
+        pop.replay_load(g, synth_rows(int(ids[g]), replay, S, A))
+    return pop
 
+
+def timed_sweep(pop, G, steps, warmup, upl, ewc, barrier):
+    """W untimed + K timed population updates; returns (seconds, kernel_ms, launches)"""
     def run_updates(k):              # k updates of every agent ("steps"), upl per launch
         full, rem = divmod(k, upl)
         for _ in range(full):
@@ -161,28 +196,121 @@ def main():
     if ewc:
         pop.update_best_param(np.ones(G))
         pop.ewc_setup()
-    run_updates(args.warmup)
+    run_updates(warmup)
     pop.sync()
+    pop.set_profiling(True)
+    pop.profile_read()
+    barrier(pop)
+    t0 = time.perf_counter()
+    run_updates(steps)
+    pop.sync()
+    barrier(pop)
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = pop.profile_read()
+    pop.set_profiling(False)
+    return dt, kernel_ms, launches
 
-    def barrier():
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--agents", type=int, default=1024, help="agents per GPU of the weak-scaling sweep")
+    ap.add_argument("--total-agents", type=int, default=1024, help="agents of the strong-scaling sweep (N > 1): the metric's 1024")
+    ap.add_argument("--size", default="mid", choices=sorted(SIZES))
+    ap.add_argument("--no-ewc", action="store_true")
+    ap.add_argument("--replay", type=int, default=10000)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sweep")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / clock reduction only (gloo, no GPU, no library)")
+    ap.add_argument("--updates-per-launch", type=int, default=8,
+                    help="consecutive updates per agent fused into one launch (ddrl_pop_ddpg_update_n): the reference's "
+                         "fupd loop, 1 + force_more_update = 8 in its ddpg.ini; bit-identical to separate launches")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)        # nothing above has touched the GPU (or imported torch)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: reporting the world that ran\n" % (args.gpus, world))
+    S, A, B = 18, 6, 64
+    ha, hq = SIZES[args.size]
+    ewc = not args.no_ewc
+    G = args.agents
+
+    # CPU baseline first: before anything initialises the GPU in this process
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu and not args.dry_run:
+        ncpu = os.cpu_count() or 1
+        threads = args.cpu_threads or min(16, ncpu)      # the GPU box gives one GPU's share: 16 cores
+        ups, n, dt = cpu_baseline(S, A, B, ha, hq, ewc, args.cpu_seconds, threads, args.replay)
+        ups1, n1, dt1 = cpu_baseline(S, A, B, ha, hq, ewc, args.cpu_seconds / 3, 1, args.replay)
+        cpu = {"value": ups, "unit": "updates/s", "cores": threads, "kind": "port",
+               "single_core": ups1, "host_cpu_count": ncpu,
+               "sample": "%d updates of the same per-agent workload (%s nets, B=64, EWC %s, replay %d) by the fp64 oracle, "
+                         "one agent per thread on %d threads, %.1f s; single core: %d updates in %.1f s"
+                         % (n, args.size, "on" if ewc else "off", args.replay, threads, dt, n1, dt1)}
+
+    import torch
+    import torch.distributed as dist
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_dt": float(t.item()),
+                              "launched_by": "bench.py" if os.environ.get("DDRL_BENCH_CHILD") else "torch.distributed.run"}))
+        return
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier(pop):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         pop.sync()
 
-    pop.set_profiling(True)
-    pop.profile_read()
-    barrier()
-    t0 = time.perf_counter()
-    run_updates(args.steps)
-    pop.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches = pop.profile_read()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    upl = max(1, min(args.updates_per_launch, 64))
+    if max(ha + hq) > 128:
+        upl = 1                      # the layer-by-layer path launches per update anyway
+
+    # ---- the weak-scaling sweep: --agents per GPU
+    pop = build_population(G, rank, rank * G, S, A, B, ha, hq, ewc, args.replay, local_rank)
+    dt, kernel_ms, launches = timed_sweep(pop, G, args.steps, args.warmup, upl, ewc, barrier)
+    dt = max_over_ranks(dt)
+    del pop
+
+    # ---- N > 1: the metric's own configuration, 1024 agents over the node (1024 / N per GPU)
+    strong = None
+    if world > 1 and not args.no_strong:
+        from ddrl_amd.shard import block_range
+        lo, hi = block_range(args.total_agents, rank, world)
+        pop = build_population(hi - lo, rank, lo, S, A, B, ha, hq, ewc, args.replay, local_rank)
+        sdt, skms, sl = timed_sweep(pop, hi - lo, args.steps, args.warmup, upl, ewc, barrier)
+        sdt = max_over_ranks(sdt)
+        strong = {"scaling": "strong", "agents_total": args.total_agents, "agents_per_gpu": hi - lo,
+                  "value": args.total_agents * args.steps / sdt, "unit": "updates/s", "ms_per_step": sdt / args.steps * 1e3,
+                  "kernel_avg_ms_rank0": skms / max(sl, 1)}
+        del pop
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -192,20 +320,7 @@ def main():
     kavg = kernel_ms * 1e-3 / max(launches, 1)          # per launch, as rocprofv3 reports it
     upl_eff = args.steps / max(launches, 1)             # updates per launch actually run
     achieved = byts * G * upl_eff / kavg
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tp):
-        try:
-            # measured HBM bytes per launch (PMC, profiles/README.md) for 1 and for 8 updates per launch; a launch with
-            # another count (--steps not a multiple of 8 leaves a shorter last launch) is priced per update from the nearer one
-            tj = json.load(open(tp))
-            per_update = {n: tj.get("bytes_per_launch_%d_%s_upl%d" % (G, args.size, n)) for n in (1, 8)}
-            per_update = {n: v / n for n, v in per_update.items() if v}
-            if per_update:
-                near = min(per_update, key=lambda n: abs(n - upl_eff))
-                traffic = per_update[near] * upl_eff
-        except Exception:
-            traffic = None
+    traffic, traffic_source = canned_traffic(G, args.size, upl_eff)
     out = {
         "metric": "actor+critic minibatch updates/sec (node), 1024-agent HalfCheetah DDPG sweep",
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,7 +332,7 @@ def main():
                                % ("+EWC" if ewc else "", args.size, "x".join(map(str, ha)), "x".join(map(str, hq)), G, args.replay, upl, upl - 1),
                    "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "ddpg_update_kernel" if max(ha + hq) <= 128 else "wide_* layer kernels, optimiser inside the dW kernels (one update = 45 launches)",
                      "kernel_avg_ms": kavg * 1e3, "launches": launches,
                      "updates_per_launch": upl_eff, "algorithmic_bytes_per_launch": byts * G * upl_eff,
@@ -225,6 +340,8 @@ def main():
                      "mfma_f32_frac": flops * G * upl_eff / kavg / MFMA_F32_PEAK, "flops_per_agent_update": flops},
         "cpu_baseline": cpu,
     }
+    if strong is not None:
+        out["strong"] = strong
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
