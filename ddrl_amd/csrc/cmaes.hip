@@ -807,6 +807,59 @@ extern "C" int ddrl_cmaes_rank(ddrl_cmaes_t *h, const double *fitness, int n, in
   return DDRL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ddrl_cmaes_rank_noalloc: ddrl_cmaes_rank for callers that cannot allocate (code under HIP graph capture,
+// serving loops, harnesses that forbid hipMalloc).  No handle, no hipMalloc / hipFree: the device staging of
+// the fitness values and of the resulting index -- h->d_fit and h->d_flag in ddrl_cmaes_rank, buffers the
+// library allocates -- lives in a file-scope device array instead.  Each GPU holds its own copy of the array
+// at its own address: the address is looked up once per device (hipGetSymbolAddress) with that device current
+// and only that pointer, never the array's name, is handed to copies and kernels.
+// Every call on a GPU shares that GPU's array: calls that overlap on one GPU race (the caller serialises them).
+// ---------------------------------------------------------------------------------------------
+#define DDRL_RANK_NOALLOC_MAX 4096           // = the largest population the LDS sort of cmaes_rank_kernel takes
+#define DDRL_RANK_SCRATCH_BYTES (DDRL_RANK_NOALLOC_MAX * (sizeof(double) + sizeof(int)))   // 48 KiB per GPU
+static __device__ __align__(256) unsigned char scratch[DDRL_RANK_SCRATCH_BYTES];
+
+static int rank_scratch_ptr(unsigned char **out) {
+  static unsigned char *per_device[64] = {};
+  int dev = -1;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ddrl_fail(DDRL_EINVAL, "device ordinal %d out of range", dev);
+  unsigned char *p = __atomic_load_n(&per_device[dev], __ATOMIC_ACQUIRE);
+  if (!p) {
+    HIPCHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+    if (!p) return ddrl_fail(DDRL_EHIP, "hipGetSymbolAddress(scratch) returned a null address");
+    __atomic_store_n(&per_device[dev], p, __ATOMIC_RELEASE);     // two first calls at once look up the same address
+  }
+  *out = p;
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_cmaes_rank_noalloc(const double *fitness, int n, int32_t *index_out, void *stream) {
+  if (!fitness || !index_out) return ddrl_fail(DDRL_EINVAL, "NULL argument");
+  if (n < 1 || n > DDRL_RANK_NOALLOC_MAX)
+    return ddrl_fail(DDRL_EINVAL, "ddrl_cmaes_rank_noalloc: n = %d outside 1..%d (the fixed scratch holds %d values)", n,
+                     DDRL_RANK_NOALLOC_MAX, DDRL_RANK_NOALLOC_MAX);
+  unsigned char *sp = nullptr;
+  int rc = rank_scratch_ptr(&sp);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  double *d_f = (double *)sp;                                          // [n] keys
+  int *d_idx = (int *)(sp + DDRL_RANK_NOALLOC_MAX * sizeof(double));   // [n] result
+  // nothing here must start at zero: the kernel reads d_f[0..n) (just copied) and writes d_idx[0..n) in full
+  HIPCHK(hipMemcpyAsync(d_f, fitness, (size_t)n * sizeof(double), hipMemcpyDefault, st));
+  int p2 = 2;
+  while (p2 < n) p2 <<= 1;
+  const size_t lds = (size_t)p2 * (sizeof(unsigned long long) + sizeof(unsigned int));
+  static LdsConfig configured;
+  HIPCHK(ddrl_set_lds(cmaes_rank_kernel, lds, configured));
+  hipLaunchKernelGGL(cmaes_rank_kernel, dim3(1), dim3(1024), lds, st, (const double *)d_f, n, p2, d_idx);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(index_out, d_idx, (size_t)n * sizeof(int), hipMemcpyDefault, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return DDRL_OK;
+}
+
 extern "C" int ddrl_cmaes_update_dev(ddrl_cmaes_t *h, const double *d_fitness) {
   if (!h || !d_fitness) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (h->state != 1) return ddrl_fail(DDRL_ESTATE, "cmaes_UpdateDistribution(): call ddrl_cmaes_sample() before the update");

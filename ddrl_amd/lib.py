@@ -186,6 +186,7 @@ SYMBOLS = [
     ("ddrl_cmaes_update", _i, [_vp, _vp]),
     ("ddrl_cmaes_update_dev", _i, [_vp, _vp]),
     ("ddrl_cmaes_rank", _i, [_vp, _vp, _i, _vp]),
+    ("ddrl_cmaes_rank_noalloc", _i, [_vp, _i, _vp, _vp]),
     ("ddrl_cmaes_get", _i, [_vp, _cp, C.POINTER(C.c_double)]),
     ("ddrl_cmaes_get_vec", _i, [_vp, _cp, _vp]),
     ("ddrl_cmaes_get_index", _i, [_vp, _vp]),

@@ -378,6 +378,14 @@ int ddrl_cmaes_update(ddrl_cmaes_t *h, const double *fitness);
 int ddrl_cmaes_update_dev(ddrl_cmaes_t *h, const double *d_fitness);
 /* Sorted_index (cmaes.c:2989-3000) on the GPU: ascending, equal values => later index first */
 int ddrl_cmaes_rank(ddrl_cmaes_t *h, const double *fitness, int n, int32_t *index_out);
+/* No counterpart in the reference: ddrl_cmaes_rank for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same ranking, same tie rule, no
+ * handle: the device staging of the fitness values and of the index lives in a fixed 48-KiB array inside the
+ * library (one per GPU, held until the process ends), so n <= 4096 (larger n: DDRL_EINVAL).  fitness [n] and
+ * index_out [n] may be host or device pointers; `stream` is a hipStream_t (NULL = the default stream) of the
+ * CURRENT device; the call returns after the result has landed.  Calls no hipMalloc / hipFree.  All calls on
+ * one GPU share that GPU's array: calls that overlap on one GPU race, the caller serialises them. */
+int ddrl_cmaes_rank_noalloc(const double *fitness, int n, int32_t *index_out, void *stream);
 /* cmaes_Get (scalars: "sigma","gen","lambda","mu","N","mueff","cs","damps","ccumcov","ccov","mucov",
  * "chiN","modulo","eigen_uptodate","countevals","fbestever") and cmaes_GetPtr-like vectors ("xmean",
  * "xbestever" (CMAESAg::getBestSolution, CMAESAg.hpp:328-335),"ps","pc","D",
