@@ -27,6 +27,7 @@ struct LdsMap {
   float *topq, *topa;        // output tiles: q [64 x 4], actions [64 x ld(A)]
   float *yv, *rv, *dn;       // TD target, reward, goal flag per row
   float *nrew; int *nvalid;  // n-step return: discounted reward prefix and horizon per row
+  float *dump;               // DDRL_NWAVES x 64 floats nobody reads: where l2_touch's loads land (mlp_device.h)
 };
 
 // gather one 64-row tile (B <= 64 rows are real: idx[0..B)) of the minibatch from the agent's replay ring (DeepQNAg.hpp:353-377,
@@ -85,7 +86,8 @@ __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &
   o.fisher_beta = P.fisher_beta;
   o.nsample = nsample;
   o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
-  o.handoff = P.nupd > 1;
+  o.dump = nullptr;
+  o.handoff = P.nupd > 1 && !P.pair;     // the pair kernel keeps an agent's consecutive updates in one workgroup
   return o;
 }
 
@@ -117,7 +119,7 @@ __device__ __forceinline__ void nstep_horizon(const DdpgParams &P, int S, int A,
     M.nvalid[tid] = valid;
     M.nrew[tid] = acc;
   }
-  __syncthreads();
+  ddrl_sync();
 }
 
 // carve LDS (same order as ddpg_update_lds_bytes)
@@ -127,6 +129,7 @@ __device__ __forceinline__ LdsMap ddpg_carve(float *p, int La, int Lq, int ldh, 
   p += ((La > Lq ? La : Lq) - 1) * M.hstride;
   M.xc = p; p += DDRL_MB * ldxc;
   M.xa = p; p += DDRL_MB * ldxa;
+  M.dump = p; p += DDRL_NWAVES * 64;     // before topq: from topq on the allocation doubles as the park area of bwd_net
   M.topq = p; p += DDRL_MB * ldq;
   M.topa = p; p += DDRL_MB * lda;
   M.yv = p; p += DDRL_MB;

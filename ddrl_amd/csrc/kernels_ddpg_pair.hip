@@ -1,0 +1,95 @@
+// kernels_ddpg_pair.hip -- the fused DDPG population update, two agents per workgroup in opposite phases.
+//
+// Why: one pass of the fupd loop (DeepQNAg.hpp:343-466) alternates between quarters that only compute (forward
+// passes, input gradients: matrix pipe busy, HBM idle) and quarters that stream the optimiser state (the backward
+// passes with the fused Adam / EWC / soft-update epilogue: HBM busy, matrix pipe mostly idle) -- ddpg_update_body.h.
+// With one workgroup per (update, agent) the two kinds of quarter of the two workgroups sharing a CU overlap only
+// by chance (measured: the times of the compute-only and the memory-only builds ADD).
+// Here a 512-thread workgroup holds TWO agents, one per 256-thread team, and walks them through all nupd updates
+// of the launch with team 1 one quarter behind team 0; a workgroup barrier after every quarter keeps them there.
+// So while one team streams its state the other one computes, on every CU, for the whole launch: HBM and the
+// matrix pipe are both busy by construction.  Inside a quarter the teams synchronise on their own (ddrl_sync with
+// DDRL_TEAMS: a counter in LDS), never on the hardware barrier.
+// An agent's consecutive updates stay on one CU, so there is no hand-off between workgroups (no sc1 stores, no
+// ordering waits, no reliance on dispatch order): the state an update reads was written by the same CU.
+// The price is one idle quarter per team and launch (1 / (4 nupd + 1)), which is why launches of fewer than
+// DDRL_PAIR_MIN_UPD updates keep the one-agent kernel (kernels_ddpg.hip).
+#define DDRL_TEAMS 1
+#include "ddpg_update_body.h"
+
+template <class NA, class NQ, bool EWC_A, bool EWC_Q>
+__global__ void __launch_bounds__(2 * DDRL_NTHREADS, 1)
+ddpg_update_pair_kernel(const DdpgParams P, int team_floats) {
+  extern __shared__ __align__(16) float lds[];
+  const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int tid = (int)threadIdx.x & (DDRL_NTHREADS - 1);
+  const int agent = 2 * (int)blockIdx.x + team;
+  if (threadIdx.x == 0) { ddrl_team_cnt[0] = 0; ddrl_team_cnt[1] = 0; ddrl_team_err = 0; }
+  bool live = agent < P.G;
+  const int ag = live ? agent : P.G - 1;
+  const uint8_t on = P.mask ? P.mask[ag] : (uint8_t)1;
+  const int len = P.rep_len[ag], head = P.rep_head[ag];
+  const float gamma = P.gamma[ag], tau = P.tau[ag], omtau = P.omtau[ag];
+  live = live && on && len >= 250 && len >= P.B;              // DeepQNAg.hpp:338
+  float *tl = lds + (size_t)team * team_floats;
+  const int nq = 4 * P.nupd;
+  __syncthreads();
+#pragma unroll 1
+  for (int t = 0; t <= nq; ++t) {
+    const int tt = t - team;                                  // team 1 runs one quarter behind team 0
+    if (live && tt >= 0 && tt < nq) {
+      const int u = tt >> 2;
+      // every quarter derives its addresses afresh from values the optimiser cannot see through: hoisted out of
+      // this loop they would all stay live across it (the four bodies together: hundreds of registers, spilled)
+      int a_it = agent, tid_it = tid, z = 0;
+      asm volatile("" : "+s"(a_it), "+s"(z));
+      asm volatile("" : "+v"(tid_it));
+      float *tl_it = tl + z;
+      switch (tt & 3) {
+        case 0: ddpg_q0<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, len, head, gamma, tid_it); break;
+        case 1: ddpg_q1<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, tau, omtau, tid_it); break;
+        case 2: ddpg_q2<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, tid_it); break;
+        default: ddpg_q3<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, tau, omtau, tid_it, false); break;
+      }
+    }
+    __syncthreads();                                          // both teams: the quarter boundary
+  }
+  if (threadIdx.x == 0 && ddrl_team_err) __hip_atomic_store(P.upd_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P);
+
+template <class NA, class NQ, bool EA, bool EQ>
+static hipError_t launch_t(const DdpgParams *P, size_t team_bytes, hipStream_t st) {
+  static LdsConfig configured;
+  const size_t lds = 2 * team_bytes;
+  hipError_t e = ddrl_set_lds(ddpg_update_pair_kernel<NA, NQ, EA, EQ>, lds, configured);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ddpg_update_pair_kernel<NA, NQ, EA, EQ>), dim3((P->G + 1) / 2), dim3(2 * DDRL_NTHREADS), lds, st, *P,
+                     (int)(team_bytes / sizeof(float)));
+  return hipGetLastError();
+}
+
+template <class NA, class NQ>
+static hipError_t launch_ewc(const DdpgParams *P, size_t team_bytes, hipStream_t st) {
+  const bool ea = P->sa.fisher != nullptr, eq = P->sq.fisher != nullptr;
+  if (ea && eq) return launch_t<NA, NQ, true, true>(P, team_bytes, st);
+  if (ea) return launch_t<NA, NQ, true, false>(P, team_bytes, st);
+  if (eq) return hipErrorInvalidValue;          // EWC on the critic alone does not exist (DODevMLP: ewc_for_critic needs ewc)
+  return launch_t<NA, NQ, false, false>(P, team_bytes, st);
+}
+
+// can this population's update run as pairs?  (compile-time shapes only: two teams of the run-time-shape kernel
+// would not fit the register file at two waves per SIMD any better than the one-agent kernel does)
+extern "C" int ddpg_update_pair_ok(const DdpgParams *P) {
+  const size_t team_bytes = (ddpg_update_lds_bytes(P) + 255) / 256 * 256;
+  if (2 * team_bytes + 64 > 160 * 1024) return 0;
+  return (MidActor::matches(P->a) && MidCritic::matches(P->q)) || (SmallActor::matches(P->a) && SmallCritic::matches(P->q));
+}
+
+extern "C" hipError_t ddpg_update_pair_launch(const DdpgParams *P, hipStream_t st) {
+  const size_t team_bytes = (ddpg_update_lds_bytes(P) + 255) / 256 * 256;
+  if (MidActor::matches(P->a) && MidCritic::matches(P->q)) return launch_ewc<MidActor, MidCritic>(P, team_bytes, st);
+  if (SmallActor::matches(P->a) && SmallCritic::matches(P->q)) return launch_ewc<SmallActor, SmallCritic>(P, team_bytes, st);
+  return hipErrorInvalidValue;
+}

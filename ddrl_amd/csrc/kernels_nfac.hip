@@ -211,6 +211,7 @@ nfac_apply_kernel(const NfacParams P, int iter_add, int last) {
   __syncthreads();
   const float nsample = MODE == 0 ? (float)T : (float)npos;
   OptCtx o;
+  o.dump = nullptr;
   const size_t off = (size_t)agent * nd.stride();
   o.w = st.w + off; o.m = st.m + off; o.v = st.v + off; o.wt = nullptr;
   o.fisher = EWC ? st.fisher + off : nullptr;

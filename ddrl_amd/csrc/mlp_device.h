@@ -25,6 +25,33 @@
 #pragma once
 #include "pop_internal.h"
 
+// The barrier of everything in these headers.  Default: the hardware workgroup barrier.  A translation unit that
+// runs TWO independent 256-thread teams inside one 512-thread workgroup (kernels_ddpg_pair.hip: two agents per
+// CU held in opposite phases) defines DDRL_TEAMS before including them: the barrier then joins the four waves of
+// the caller's team only, through a counter in LDS (gfx950 has no named barriers).  The counter only grows: a
+// wave arriving as number `old` of its team waits for the count to reach the next multiple of four.  The wait is
+// bounded; on expiry team_err is raised and the kernel reports it (results are then undefined, but it ends).
+#ifdef DDRL_TEAMS
+__shared__ unsigned ddrl_team_cnt[2];
+__shared__ int ddrl_team_err;
+__device__ __forceinline__ void ddrl_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS and global accesses are done before it arrives
+  if ((threadIdx.x & 63) == 0) {
+    unsigned *cnt = &ddrl_team_cnt[threadIdx.x >> 8];
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned target = (old & ~3u) + 4u;
+    int spins = 0;
+    while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { ddrl_team_err = 1; break; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#else
+__device__ __forceinline__ void ddrl_sync() { __syncthreads(); }
+#endif
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -36,6 +63,30 @@ __device__ __forceinline__ const float *opaque(const float *p) {
   int z = 0;
   asm volatile("" : "+s"(z));      // an offset of 0 the optimiser cannot see; the address space of p is kept
   return p + z;
+}
+
+// Cache warming without registers (EXPERIMENT switches DDRL_EXP_TOUCHW / DDRL_EXP_TOUCHSTATE only, never defined in the
+// product): an LDS-DMA load of ONE dword per lane whose destination is a 256-byte dump area of LDS that nobody reads.
+// Lane i's address names the 128-byte line to pull toward this CU, so one wave instruction covers 8 KiB of a
+// contiguous array.  Tried for the weights of the coming passes and for the optimiser state ahead of the fused
+// epilogue; both made the update SLOWER (507 vs 496 us and 615 vs 496 us per update): the
+// launch is bound by the bytes a CU can pull in, not by the latency of single loads, and a touch is one more request.
+// The statement is invisible to the compiler's s_waitcnt bookkeeping, which only makes its waits conservative
+// (vector memory operations complete in issue order); nothing ever waits for the dump itself.
+__device__ __forceinline__ void l2_touch(const float *p, float *dump_wave) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)dump_wave);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+}
+// touch every 128-byte line of `floats` contiguous floats, the lines dealt to the DDRL_NTHREADS threads of the team
+__device__ __forceinline__ void l2_touch_block(const float *base, int floats, float *dump, int tid) {
+  float *dw = dump + (tid >> 6) * 64;
+  for (int i0 = 0; i0 < floats; i0 += 32 * DDRL_NTHREADS) {
+    int i = i0 + 32 * tid;
+    if (i >= floats) i = floats - 32 > 0 ? floats - 32 : 0;       // clamped, never out of the block
+    l2_touch(base + i, dw);
+  }
 }
 
 // Caffe ReLULayer (negative_slope 0.01 for hidden_layer_type 1, MLP.hpp:888-897), TanHLayer
@@ -246,6 +297,7 @@ struct OptCtx {
   const float *fhat, *wstar;
   float lr_t, tau, omtau, decay, ewc_coef, fisher_beta, nsample;
   float beta1, beta2, omb1, omb2, eps;
+  float *dump;       // LDS dump area for l2_touch (null: none)
   int handoff;       // the state is read by ANOTHER workgroup later in this launch (multi-update launches): sc1 stores
 };
 
@@ -473,6 +525,24 @@ __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ld
   OptRegs1 rb;
   const int nb = tid < N ? tid : N - 1;
   opt_load1<EWC, TGT>(o, offb + nb, rb);
+#ifdef DDRL_EXP_TOUCHSTATE
+  if (o.dump) {
+    // this wave's slice of the layer (tiles p0 .. p0 + per - 1 are contiguous in the tile-major layout) toward the caches
+    int nt0 = (p0 < total ? p0 : total - 1) / KT, kt0 = (p0 < total ? p0 : total - 1) - nt0 * KT;
+    const int lo = offw + ddrl_tile_base(nt0, kt0, kp);
+    const int pe = p0 + per < total ? p0 + per : total;
+    int hi = offw + ddrl_wsize(N, kp);
+    if (pe < total) { const int nt1 = pe / KT, kt1 = pe - nt1 * KT; hi = offw + ddrl_tile_base(nt1, kt1, kp); }
+    float *dw = o.dump + wave * 64;
+    for (int i0 = lo; i0 < hi; i0 += 32 * 64) {
+      int i = i0 + 32 * lane;
+      if (i >= hi) i = hi - 32 > lo ? hi - 32 : lo;
+      l2_touch(o.w + i, dw); l2_touch(o.m + i, dw); l2_touch(o.v + i, dw);
+      if (TGT) l2_touch(o.wt + i, dw);
+      if (EWC) { l2_touch(o.fisher + i, dw); l2_touch(o.fhat + i, dw); l2_touch(o.wstar + i, dw); }
+    }
+  }
+#endif
   if (SETS3) {
     // Three sets in rotation: the state of tile s + 2 is requested before tile s is computed (a tile
     // of products + Adam is ~1.2k cycles, an HBM round trip 4-6k).  Used where the registers allow

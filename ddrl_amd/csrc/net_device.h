@@ -75,7 +75,7 @@ __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__rest
       ldi = ldo;
     }
   }
-  __syncthreads();
+  ddrl_sync();
 }
 
 // a pass on its own: nothing requested ahead, nothing handed over
@@ -121,7 +121,7 @@ __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w
     if (need_dx) bwd_dx(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
     if (bst && tid == 0 && ll < 2) bst[2 * ll] = clock64();
     if (TRAIN != DW_NONE) {
-      __syncthreads();   // every wave's rows of dZ_l are final and every wave has read W_l
+      ddrl_sync();   // every wave's rows of dZ_l are final and every wave has read W_l
       if (TRAIN == DW_OPT) {
         // Below the top layer the first DDRL_PARK_TILES input-gradient tiles wait in LDS while the
         // optimiser loop runs, which makes room for its third state set (the first layer has no
@@ -142,7 +142,7 @@ __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w
       }
       else bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid);
       if (bst && tid == 0 && ll < 2) bst[2 * ll + 1] = clock64();
-      __syncthreads();   // every wave has read H_{l-1} before its rows are overwritten by dZ_{l-1}
+      ddrl_sync();   // every wave has read H_{l-1} before its rows are overwritten by dZ_{l-1}
     }
     if (need_dx) {
 #pragma unroll

@@ -9,6 +9,7 @@
 #define DDRL_NWAVES 4        // 256-thread workgroups, one wave per SIMD: each wave carries 16 of the 64 batch rows (mlp_device.h);
 #endif                       // two workgroups per CU (LDS, and 256 VGPRs per wave) => two waves per SIMD
 #define DDRL_NTHREADS (DDRL_NWAVES * 64)
+#define DDRL_PAIR_MIN_UPD 4     // shortest launch (updates per agent) that runs as agent pairs (kernels_ddpg_pair.hip: one idle quarter per launch)
 #define DDRL_MAXUPD 64       // consecutive updates one launch may run (ddrl_pop_ddpg_update_n)
 #define DDRL_MAXB 4096       // largest minibatch (chunks of DDRL_MB rows, kernels_ddpg_big.hip)
 #define DDRL_WIDE_MAXW 1024  // widest layer of the layer-by-layer kernels (kernels_ddpg_wide.hip)
@@ -147,6 +148,7 @@ struct DdpgParams {
   int nupd;                 // consecutive updates per launch (>= 1): idx is [G x nupd x B], lr_t [G x nupd]
   int *upd_done;            // [G] updates of this launch an agent has completed (zeroed by the prep kernel)
   int *upd_error;           // [1] raised when a workgroup gave up waiting for its predecessor
+  int pair;                 // launched as ddpg_update_pair_kernel (kernels_ddpg_pair.hip): an agent's nupd updates stay in one workgroup
 };
 
 // NFAC(lambda)-V kernels (kernels_nfac.hip)

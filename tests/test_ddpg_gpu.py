@@ -373,12 +373,16 @@ def test_xcd_order_many_agents(ora, G, B, hidden_a, hidden_q):
         check_step(pop, agents, ws_prev, _hyper(agents), 0, TOL, allow_kink=True)
 
 
+@pytest.mark.parametrize("pair", [1, 0])
 @pytest.mark.parametrize("B,hidden,kw", [(64, (100, 100), dict()), (32, (20,), dict(nstep_return=2, goal_prob=0.1)), (96, (24, 16), dict())])
-def test_fused_consecutive_updates(ora, B, hidden, kw):
+def test_fused_consecutive_updates(ora, B, hidden, kw, pair):
     """ddrl_pop_ddpg_update_n: n passes of the fupd loop in one launch (one-tile minibatches) == n calls of
-    ddrl_pop_ddpg_update, bit for bit, including the replay-index stream; and against the oracle."""
+    ddrl_pop_ddpg_update, bit for bit, including the replay-index stream; and against the oracle.  pair = 1: launches
+    of >= 4 updates of the compile-time shapes run as agent pairs (kernels_ddpg_pair.hip; G = 3 leaves one team
+    without an agent, the mask another one idle); pair = 0: one workgroup per (update, agent) with the sc1 hand-off."""
     G, n = 3, 4
     popa, agents = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
+    popa.set_option("pair", pair)
     popb, _ = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
     mask = np.array([1, 0, 1], np.uint8)
     popa.update_n(n, mask=mask)
@@ -413,13 +417,15 @@ def test_fused_consecutive_updates(ora, B, hidden, kw):
             assert close_frac(w[g], wo[g], 1e-4, 0.99, 1e-2), (net, g)
 
 
-def test_fused_consecutive_updates_full_chip():
-    """the same identity at the bench's scale: 8 x 1100 workgroups against 512 resident slots, so an agent's
-    consecutive updates run in different dispatch rounds, on different CUs and XCDs (the sc1 hand-off), EWC live;
-    and the diagnostics are those of the LAST update"""
+@pytest.mark.parametrize("pair", [1, 0])
+def test_fused_consecutive_updates_full_chip(pair):
+    """the same identity at the bench's scale, EWC live.  pair = 0: 8 x 1100 workgroups against 512 resident slots, so
+    an agent's consecutive updates run in different dispatch rounds, on different CUs and XCDs (the sc1 hand-off);
+    pair = 1: 551 workgroups of two agents each, one quarter of an update apart, an odd agent count (the last
+    workgroup's second team has no agent).  The diagnostics are those of the LAST update"""
     import ddrl_amd
     from bench import synth_rows
-    G, n = 1100, 8
+    G, n = 1101, 8
     pops = []
     for _ in range(2):
         cfg = ddrl_amd.DdpgConfig(n_agents=G, replay_memory=600, ewc=100.0, ewc_decay=-1.0, ewc_for_critic=1)
@@ -434,6 +440,7 @@ def test_fused_consecutive_updates_full_chip():
         p.update_best_param(np.ones(G)); p.ewc_setup()
         pops.append(p)
     a, b = pops
+    a.set_option("pair", pair)
     for _ in range(2):
         a.update_n(n)
         for _ in range(n):
