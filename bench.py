@@ -103,6 +103,7 @@ def cpu_baseline(S, A, B, ha, hq, ewc, seconds, threads, replay):
 
 
 PAIR_MODE = 1
+RESIDENT = 0
 KERNEL_SOURCES = ("kernels_ddpg.hip", "kernels_ddpg_pair.hip", "ddpg_update_body.h", "ddpg_device.h", "net_device.h", "mlp_device.h", "pop_internal.h")
 
 
@@ -173,6 +174,7 @@ def build_population(G, rank, first_agent, S, A, B, ha, hq, ewc, replay, local_r
                               ewc_for_critic=1, ewc_best_param_method=0, device=local_rank)
     pop = ddrl_amd.DdpgPopulation(cfg, init_seed=2000 + rank)
     pop.set_option("pair", PAIR_MODE)
+    pop.set_option("resident", RESIDENT)
     # per-agent hyper-parameters and replay depend on the agent's id in the whole sweep, not on the sharding
     ids = first_agent + np.arange(G)
     hyp = np.array([np.random.RandomState(3000 + i).uniform(size=3) for i in ids]).reshape(G, 3)
@@ -228,13 +230,15 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sweep")
     ap.add_argument("--pair", type=int, default=1, help="0: one agent per workgroup always; 1: agent pairs for launches of >= 4 updates; 2: pairs whenever they fit")
+    ap.add_argument("--resident", type=int, default=0, help="1: small nets keep an agent's state in LDS over a multi-update launch")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / clock reduction only (gloo, no GPU, no library)")
     ap.add_argument("--updates-per-launch", type=int, default=8,
                     help="consecutive updates per agent fused into one launch (ddrl_pop_ddpg_update_n): the reference's "
                          "fupd loop, 1 + force_more_update = 8 in its ddpg.ini; bit-identical to separate launches")
     args = ap.parse_args()
-    global PAIR_MODE
+    global PAIR_MODE, RESIDENT
     PAIR_MODE = args.pair
+    RESIDENT = args.resident
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)        # nothing above has touched the GPU (or imported torch)

@@ -73,7 +73,7 @@ template <bool EWC>
 __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &s, int stride,
                                            int agent, float tau, float omtau, float nsample, int u = 0) {
   OptCtx o;
-  const size_t off = (size_t)agent * stride;
+  const size_t off = P.resident ? 0 : (size_t)agent * stride;
   o.w = s.w + off; o.m = s.m + off; o.v = s.v + off;
   o.wt = s.wt + off;
   o.fisher = EWC ? s.fisher + off : nullptr;

@@ -36,8 +36,9 @@ __device__ __forceinline__ UpdView<NA, NQ> upd_view(const DdpgParams &P, float *
   V.M = ddpg_carve(lds, na.L(), nq.L(), P.ldh, V.ldxc, V.ldxa, V.ldq, V.lda);
   V.stamps = P.stamps ? P.stamps + (size_t)agent * 16 : nullptr;
   V.agate = P.agate ? P.agate + (size_t)agent * V.A : nullptr;
-  V.w_a = P.sa.w + (size_t)agent * na.stride(); V.w_at = P.sa.wt + (size_t)agent * na.stride();
-  V.w_q = P.sq.w + (size_t)agent * nq.stride(); V.w_qt = P.sq.wt + (size_t)agent * nq.stride();
+  const size_t sa = P.resident ? 0 : (size_t)agent;      // resident: the state arrays are one agent's LDS copy
+  V.w_a = P.sa.w + sa * na.stride(); V.w_at = P.sa.wt + sa * na.stride();
+  V.w_q = P.sq.w + sa * nq.stride(); V.w_qt = P.sq.wt + sa * nq.stride();
 #ifdef DDRL_EXP_HOTW      // experiment: every agent's passes read agent 0's weights (always cache-hot)
   V.w_a = P.sa.w; V.w_at = P.sa.wt; V.w_q = P.sq.w; V.w_qt = P.sq.wt;
 #endif

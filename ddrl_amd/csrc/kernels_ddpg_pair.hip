@@ -58,6 +58,70 @@ ddpg_update_pair_kernel(const DdpgParams P, int team_floats) {
 }
 
 extern "C" size_t ddpg_update_lds_bytes(const DdpgParams *P);
+// ---------------------------------------------------------------------------------------------------------------
+// Small nets: the agent's WHOLE state in LDS for the launch.  north_star: "weights and optimizer state are staged in
+// LDS where they fit".  The BASELINE "small" nets (a = 20, q = 50 x 7) hold 3 584 padded floats per array, 7 arrays
+// with EWC live (w, m, v, target, Fisher, F-hat, w*) = 98 KiB beside 45 KiB of activations: one workgroup per CU
+// copies its agent's arrays in once, runs the launch's nupd updates on the LDS copy -- the passes read their
+// weights from LDS, the fused optimiser epilogue reads and writes LDS -- and writes the five arrays that change
+// back once.  HBM traffic per agent drops from 52 B/param per UPDATE to 48 B/param per LAUNCH (+ the minibatch
+// rows), so the bound is no longer HBM but the matrix pipe / LDS.  Same device code as the other two kernels: the
+// NetState pointers of a local copy of the parameters are redirected to the LDS copy (generic pointers into the LDS
+// aperture; the optimiser addresses them as flat memory).  Results are bit-identical to nupd separate launches.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_copy(float *dst, const float *src, int floats, int tid) {   // floats % 4 == 0, 16-B aligned
+  for (int i = 4 * tid; i < floats; i += 4 * DDRL_NTHREADS) *(f32x4 *)(dst + i) = *(const f32x4 *)(src + i);
+}
+
+template <class NA, class NQ, bool EWC_A, bool EWC_Q>
+__global__ void __launch_bounds__(DDRL_NTHREADS, 1)
+ddpg_update_resident_kernel(const DdpgParams P, int act_floats) {
+  extern __shared__ __align__(16) float lds[];
+  const int tid = (int)threadIdx.x;
+  const int agent = (int)blockIdx.x;
+  if (tid == 0) { ddrl_team_cnt[0] = 0; ddrl_team_cnt[1] = 0; ddrl_team_err = 0; }
+  const uint8_t on = P.mask ? P.mask[agent] : (uint8_t)1;
+  const int len = P.rep_len[agent], head = P.rep_head[agent];
+  const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
+  if (!on || len < 250 || len < P.B) return;                  // DeepQNAg.hpp:338 (uniform: the whole workgroup leaves)
+  constexpr int SA = NA::stride(), SQ = NQ::stride();
+  float *st = lds + act_floats;
+  DdpgParams Q = P;
+  Q.resident = 1;
+  const size_t oa = (size_t)agent * SA, oq = (size_t)agent * SQ;
+  float *p = st;
+  auto stage = [&](float *&field, float *global, size_t off, int floats) {   // one array: copy in, redirect
+    block_copy(p, global + off, floats, tid);
+    field = p;
+    p += floats;
+  };
+  stage(Q.sa.w, P.sa.w, oa, SA); stage(Q.sa.m, P.sa.m, oa, SA); stage(Q.sa.v, P.sa.v, oa, SA); stage(Q.sa.wt, P.sa.wt, oa, SA);
+  stage(Q.sq.w, P.sq.w, oq, SQ); stage(Q.sq.m, P.sq.m, oq, SQ); stage(Q.sq.v, P.sq.v, oq, SQ); stage(Q.sq.wt, P.sq.wt, oq, SQ);
+  if (EWC_A) { stage(Q.sa.fisher, P.sa.fisher, oa, SA); stage(Q.sa.fhat, P.sa.fhat, oa, SA); stage(Q.sa.wstar, P.sa.wstar, oa, SA); }
+  if (EWC_Q) { stage(Q.sq.fisher, P.sq.fisher, oq, SQ); stage(Q.sq.fhat, P.sq.fhat, oq, SQ); stage(Q.sq.wstar, P.sq.wstar, oq, SQ); }
+  __syncthreads();
+#pragma unroll 1
+  for (int u = 0; u < P.nupd; ++u) {
+    int a_it = agent, tid_it = tid, z = 0;                    // see ddpg_update_pair_kernel: nothing is hoisted out of this loop
+    asm volatile("" : "+s"(a_it), "+s"(z));
+    asm volatile("" : "+v"(tid_it));
+    float *tl = lds + z;
+    ddpg_q0<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, len, head, gamma, tid_it);
+    ddpg_q1<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, tau, omtau, tid_it);
+    ddpg_q2<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, tid_it);
+    ddpg_q3<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, tau, omtau, tid_it, false);
+    ddrl_sync();
+  }
+  // what an update changes goes back (F-hat and w* are read-only here)
+  block_copy(P.sa.w + oa, Q.sa.w, SA, tid); block_copy(P.sa.m + oa, Q.sa.m, SA, tid); block_copy(P.sa.v + oa, Q.sa.v, SA, tid);
+  block_copy(P.sa.wt + oa, Q.sa.wt, SA, tid);
+  block_copy(P.sq.w + oq, Q.sq.w, SQ, tid); block_copy(P.sq.m + oq, Q.sq.m, SQ, tid); block_copy(P.sq.v + oq, Q.sq.v, SQ, tid);
+  block_copy(P.sq.wt + oq, Q.sq.wt, SQ, tid);
+  if (EWC_A) block_copy(P.sa.fisher + oa, Q.sa.fisher, SA, tid);
+  if (EWC_Q) block_copy(P.sq.fisher + oq, Q.sq.fisher, SQ, tid);
+  if (tid == 0 && ddrl_team_err) __hip_atomic_store(P.upd_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 
 template <class NA, class NQ, bool EA, bool EQ>
 static hipError_t launch_t(const DdpgParams *P, size_t team_bytes, hipStream_t st) {
@@ -93,3 +157,33 @@ extern "C" hipError_t ddpg_update_pair_launch(const DdpgParams *P, hipStream_t s
   if (SmallActor::matches(P->a) && SmallCritic::matches(P->q)) return launch_ewc<SmallActor, SmallCritic>(P, team_bytes, st);
   return hipErrorInvalidValue;
 }
+
+// ---- the resident kernel's host side ----
+static size_t resident_state_floats(const DdpgParams *P) {
+  const size_t per = (size_t)P->a.stride_ + P->q.stride_;
+  return 4 * per + (P->sa.fisher ? 3 * (size_t)P->a.stride_ : 0) + (P->sq.fisher ? 3 * (size_t)P->q.stride_ : 0);
+}
+extern "C" int ddpg_update_resident_ok(const DdpgParams *P) {
+  if (!(SmallActor::matches(P->a) && SmallCritic::matches(P->q))) return 0;
+  if (P->sq.fisher && !P->sa.fisher) return 0;
+  const size_t act = (ddpg_update_lds_bytes(P) + 255) / 256 * 256;
+  return act + resident_state_floats(P) * sizeof(float) + 64 <= 160 * 1024;
+}
+template <bool EA, bool EQ>
+static hipError_t launch_resident_t(const DdpgParams *P, hipStream_t st) {
+  static LdsConfig configured;
+  const size_t act = (ddpg_update_lds_bytes(P) + 255) / 256 * 256;
+  const size_t lds = act + resident_state_floats(P) * sizeof(float);
+  hipError_t e = ddrl_set_lds(ddpg_update_resident_kernel<SmallActor, SmallCritic, EA, EQ>, lds, configured);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ddpg_update_resident_kernel<SmallActor, SmallCritic, EA, EQ>), dim3(P->G), dim3(DDRL_NTHREADS), lds, st, *P,
+                     (int)(act / sizeof(float)));
+  return hipGetLastError();
+}
+extern "C" hipError_t ddpg_update_resident_launch(const DdpgParams *P, hipStream_t st) {
+  const bool ea = P->sa.fisher != nullptr, eq = P->sq.fisher != nullptr;
+  if (ea && eq) return launch_resident_t<true, true>(P, st);
+  if (ea) return launch_resident_t<true, false>(P, st);
+  return launch_resident_t<false, false>(P, st);
+}
+

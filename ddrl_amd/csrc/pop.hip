@@ -8,6 +8,8 @@ hipError_t ddpg_update_launch(const DdpgParams *P, int force_generic, hipStream_
 size_t ddpg_update_lds_bytes(const DdpgParams *P);
 hipError_t ddpg_update_pair_launch(const DdpgParams *P, hipStream_t st);
 int ddpg_update_pair_ok(const DdpgParams *P);
+hipError_t ddpg_update_resident_launch(const DdpgParams *P, hipStream_t st);
+int ddpg_update_resident_ok(const DdpgParams *P);
 hipError_t ddpg_update_big_launch(const DdpgParams *P, hipStream_t st);
 hipError_t ddpg_update_wide_launch(const DdpgParams *P, hipStream_t st);
 size_t ddpg_wide_block_floats(const DdpgParams *P);
@@ -646,7 +648,12 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   // launches of several updates: two agents per workgroup, one quarter of an update apart (kernels_ddpg_pair.hip)
   const bool pair = fused && !h->force_generic && h->pair_mode > 0 && (per_launch >= DDRL_PAIR_MIN_UPD || h->pair_mode == 2) &&
                     ddpg_update_pair_ok(&h->P);
-  h->P.pair = pair ? 1 : 0;
+  // small nets: the agent's whole state in LDS for the launch (worth the copy in / out from two updates on)
+  // (opt-in, "resident" option: measured SLOWER than the one-agent kernel -- one workgroup per CU instead of three,
+  // and the small nets' update is bound by its chain of tiny dependent passes, not by HBM: DESIGN.md section 4.1e)
+  const bool resident = fused && !h->force_generic && h->resident_mode > 0 && per_launch >= 2 &&
+                        !h->P.stamps && ddpg_update_resident_ok(&h->P);
+  h->P.pair = pair || resident ? 1 : 0;
   std::vector<int32_t> one;
   for (int l = 0; l < n; l += per_launch) {
     if (idx) {
@@ -675,6 +682,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
     }
     if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
     else if (!fused) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
+    else if (resident) HIPCHK(ddpg_update_resident_launch(&h->P, h->stream));
     else if (pair) HIPCHK(ddpg_update_pair_launch(&h->P, h->stream));
     else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
     if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
@@ -1092,6 +1100,7 @@ extern "C" int ddrl_pop_debug_stamps(ddrl_pop_t *h, int enable, long long *out) 
 extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
   if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (std::string(key) == "force_generic") { h->force_generic = value != 0; return DDRL_OK; }
+  if (std::string(key) == "resident") { h->resident_mode = value != 0; return DDRL_OK; }
   if (std::string(key) == "pair") { h->pair_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "force_chunked") {     // the gradient + apply kernels of the large-minibatch path on one-tile minibatches
     DDPG_ONLY(h);

@@ -78,6 +78,7 @@ struct ddrl_pop {
   // measurement
   bool profiling = false;
   int force_generic = 0;
+  int resident_mode = 0;      // 1: small nets keep an agent's whole state in LDS for a multi-update launch (ddpg_update_resident_kernel)
   int pair_mode = 1;          // 0: never the two-agents-per-workgroup kernel, 1: for launches of >= DDRL_PAIR_MIN_UPD updates, 2: whenever it fits
   bool force_chunked = false;
   bool wide = false;               // some layer is wider than DDRL_MAXW: layer-by-layer update kernels

@@ -148,6 +148,7 @@ struct DdpgParams {
   int nupd;                 // consecutive updates per launch (>= 1): idx is [G x nupd x B], lr_t [G x nupd]
   int *upd_done;            // [G] updates of this launch an agent has completed (zeroed by the prep kernel)
   int *upd_error;           // [1] raised when a workgroup gave up waiting for its predecessor
+  int resident;             // the NetState arrays w, m, v, wt, fisher, fhat, wstar point at ONE agent's block (LDS copy, ddpg_update_resident_kernel): no per-agent offset
   int pair;                 // launched as ddpg_update_pair_kernel (kernels_ddpg_pair.hip): an agent's nupd updates stay in one workgroup
 };
 

@@ -417,6 +417,42 @@ def test_fused_consecutive_updates(ora, B, hidden, kw, pair):
             assert close_frac(w[g], wo[g], 1e-4, 0.99, 1e-2), (net, g)
 
 
+@pytest.mark.parametrize("ewc", [True, False])
+def test_resident_small_nets(ora, ewc):
+    """BASELINE's small nets (a = 20, q = 50 x 7): with the "resident" option launches of two or more updates keep the
+    agent's whole state in LDS (ddpg_update_resident_kernel) -- bit-identical to separate launches of the one-agent kernel (weights, targets, Adam
+    state, Fisher, iteration counters, diagnostics), with and without EWC live, masked agents untouched."""
+    G, n = 5, 3
+    kw = dict(ewc=100.0, ewc_for_critic=1) if ewc else {}
+    popa, _ = make_pair(ora, G=G, B=64, hidden_a=(20,), hidden_q=(50, 7), wscale=0.1, sweep=True, seed=9, **kw)
+    popb, _ = make_pair(ora, G=G, B=64, hidden_a=(20,), hidden_q=(50, 7), wscale=0.1, sweep=True, seed=9, **kw)
+    mask = np.array([1, 1, 0, 1, 1], np.uint8)
+    for p in (popa, popb):
+        p.update()
+        if ewc:
+            p.update_best_param(np.ones(G)); p.ewc_setup()
+    popa.set_option("resident", 1)
+    popb.set_option("pair", 0)
+    for rnd in range(2):
+        popa.update_n(n, mask=mask)
+        for _ in range(n):
+            popb.update(mask=mask)
+    for net in range(4):
+        assert np.array_equal(popa.weights(net), popb.weights(net)), net
+    for net in (0, 1):
+        for x, y in zip(popa.adam(net), popb.adam(net)):
+            assert np.array_equal(x, y)
+        if ewc:
+            sa, sb = popa.ewc_state(net), popb.ewc_state(net)
+            assert np.array_equal(sa["fisher"], sb["fisher"]) and np.array_equal(sa["fisher_nbr"], sb["fisher_nbr"])
+    la, lb = popa.last(), popb.last()
+    for g in range(G):
+        if mask[g]:
+            for k in la:
+                assert np.array_equal(la[k][g], lb[k][g]), (k, g)
+    assert list(popa.adam(0)[2]) == [1 + 2 * n, 1 + 2 * n, 1, 1 + 2 * n, 1 + 2 * n]
+
+
 @pytest.mark.parametrize("pair", [1, 0])
 def test_fused_consecutive_updates_full_chip(pair):
     """the same identity at the bench's scale, EWC live.  pair = 0: 8 x 1100 workgroups against 512 resident slots, so
