@@ -56,6 +56,7 @@ nfac_values_kernel(const NfacParams P) {
   const float *w = P.sv.w + (size_t)agent * nv.stride();
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
+    if (!((P.value_passes >> pass) & 1)) continue;     // uniform
     load_states(traj, P.rowlen, T, row0, pass == 0 ? 0 : P.S + 2 * P.A, P.S, ldx,
                 P.sgate ? P.sgate + (size_t)agent * P.S : nullptr, M.x, tid);
     __syncthreads();
@@ -171,7 +172,8 @@ nfac_grad_kernel(const NfacParams P) {
       if (mode) {
         const float target = traj[(size_t)li * P.rowlen + P.S + (mode == 1 ? A : 0) + h];
         diff = -(target - out);
-        if (P.inverting) {
+        if (P.corrected) diff *= P.corr_factor;                          // OfflineCaclaAg.hpp:561-563
+        else if (P.inverting) {
           if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
           else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
         }
@@ -242,6 +244,24 @@ nfac_apply_kernel(const NfacParams P, int iter_add, int last) {
   }
 }
 
+// vnn_from_scratch (OfflineCaclaAg.hpp:281-284): the critic of every agent with a trajectory is replaced by the freshly
+// drawn net in `fresh` (same layout, pads zero), its Adam moments zeroed; iter_base[agent] receives the solver's old
+// iteration count so that the steps that follow count from a new solver (nfac_apply_kernel adds iter_add to iter).
+__global__ void __launch_bounds__(256)
+nfac_reinit_kernel(const NfacParams P, const float *__restrict__ fresh) {
+  const int agent = blockIdx.y;
+  if (P.mask && !P.mask[agent]) return;
+  if (P.len[agent] <= 0) return;
+  const int stride = P.v.stride();
+  const size_t off = (size_t)agent * stride;
+  for (int i = 4 * (blockIdx.x * 256 + threadIdx.x); i < stride; i += 4 * 256 * gridDim.x) {
+    *(f32x4 *)(P.sv.w + off + i) = *(const f32x4 *)(fresh + off + i);
+    *(f32x4 *)(P.sv.m + off + i) = zero4();
+    *(f32x4 *)(P.sv.v + off + i) = zero4();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.sv.iter[agent] = 0;       // a new solver
+}
+
 // Solver::iter after the update: + number_fitted_iteration * stoch_iter_critic for the critic,
 // + stoch_iter_actor for the actor when at least one transition had a positive advantage
 __global__ void nfac_finish_kernel(const NfacParams P, int critic_steps, int actor_steps) {
@@ -298,6 +318,11 @@ extern "C" hipError_t nfac_apply_launch(const NfacParams *P, int mode, int iter_
     if (ewc) hipLaunchKernelGGL((nfac_apply_kernel<1, true>), grid, dim3(256), 0, st, *P, iter_add, last);
     else hipLaunchKernelGGL((nfac_apply_kernel<1, false>), grid, dim3(256), 0, st, *P, iter_add, last);
   }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nfac_reinit_launch(const NfacParams *P, const float *fresh, hipStream_t st) {
+  hipLaunchKernelGGL(nfac_reinit_kernel, dim3(4, P->G), dim3(256), 0, st, *P, fresh);
   return hipGetLastError();
 }
 

@@ -3,6 +3,8 @@
 // (/root/reference/agent/cacla/include/OfflineCaclaAg.hpp:403-595).  All arithmetic is in
 // kernels_nfac.hip; there is no CPU path.
 #include "pop_host.h"
+#include <random>
+#include <sstream>
 
 extern "C" {
 size_t nfac_lds_need(const NfacParams *P);
@@ -11,6 +13,7 @@ hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen, hipStream
 hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, hipStream_t st);
 hipError_t nfac_apply_launch(const NfacParams *P, int mode, int iter_add, int last, hipStream_t st);
 hipError_t nfac_finish_launch(const NfacParams *P, int critic_steps, int actor_steps, hipStream_t st);
+hipError_t nfac_reinit_launch(const NfacParams *P, const float *fresh, hipStream_t st);
 }
 
 struct NfacHost {
@@ -26,6 +29,8 @@ struct NfacHost {
         *d_loss_part = nullptr, *d_loss = nullptr, *d_pa = nullptr;
   uint8_t *d_rowmode = nullptr;
   int *d_npos = nullptr;
+  float *d_fresh = nullptr;                   // vnn_from_scratch: the freshly drawn critics of one fitted iteration [G x stride]
+  std::mt19937_64 scratch_eng;                // ... and the engine they come from
 };
 
 void ddrl_nfac_host_free(NfacHost *n) { delete n; }
@@ -43,6 +48,8 @@ extern "C" int ddrl_nfac_config_default(ddrl_nfac_config *c) {
   c->gamma = 0.99; c->lambda = 0.9; c->alpha_a = 1e-4; c->alpha_v = 1e-3;
   c->ewc = -1.; c->ewc_decay = -1.; c->ewc_fisher_beta = 0.999; c->ewc_best_param_method = 0; c->ewc_for_critic = 0;
   c->device = -1;
+  c->vnn_from_scratch = 0; c->corrected_update_ac = 0;
+  c->corrected_update_ac_factor = 1.;      // (the reference leaves it uninitialised when the key is missing, OfflineCaclaAg.hpp:171-176,676)
   return DDRL_OK;
 }
 
@@ -79,8 +86,13 @@ extern "C" int ddrl_nfac_config_from_ini(const char *path, ddrl_nfac_config *c) 
     c->alpha_v = ini.get_double("agent.alpha_v");
     c->lambda = ini.get_double("agent.lambda");
     c->momentum = (int)ini.get_long("agent.momentum");
+    c->vnn_from_scratch = ini.get_bool("agent.vnn_from_scratch");        // mandatory like the others (:129)
     // optional keys with the reference's defaults (:142-179)
     c->gae = 0; c->inverting_gradient = 0;
+    c->corrected_update_ac = 0;
+    if (ini.has("agent.corrected_update_ac")) c->corrected_update_ac = ini.get_bool("agent.corrected_update_ac");
+    if (c->corrected_update_ac && ini.has("agent.corrected_update_ac_factor"))
+      c->corrected_update_ac_factor = ini.get_double("agent.corrected_update_ac_factor");
     if (ini.has("agent.inverting_gradient")) c->inverting_gradient = ini.get_bool("agent.inverting_gradient");
     if (c->lambda >= 0.) c->gae = ini.get_bool("agent.gae");
     if (ini.has("devnn.ewc")) c->ewc = ini.get_double("devnn.ewc");
@@ -112,6 +124,8 @@ static int nfac_validate(const ddrl_nfac_config *c) {
   if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
   if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
   if (c->number_fitted_iteration < 0 || c->stoch_iter_actor < 0 || c->stoch_iter_critic < 0) return ddrl_fail(DDRL_EINVAL, "negative iteration count");
+  if (c->vnn_from_scratch && c->ewc >= 0. && c->ewc_for_critic >= 1)
+    return ddrl_fail(DDRL_EINVAL, "vnn_from_scratch with EWC on the critic: the reference's re-created critic has no EWC state (OfflineCaclaAg.hpp:281-284)");
   if (c->max_trajectory < 1 || c->max_trajectory > 32768) return ddrl_fail(DDRL_EINVAL, "max_trajectory outside 1..32768 (the lambda-return scan is LDS resident)");
   return DDRL_OK;
 }
@@ -205,6 +219,11 @@ extern "C" int ddrl_nfac_create(const ddrl_nfac_config *cfg, uint64_t init_seed,
   for (int k = 0; k < 2; ++k)
     for (int l = 1; l < h->net[k].nd.L(); ++l) P.ldh = std::max(P.ldh, h->net[k].nd.ld(l));
   P.inverting = cfg->inverting_gradient ? 1 : 0;
+  P.corrected = cfg->corrected_update_ac ? 1 : 0;
+  P.corr_factor = (float)cfg->corrected_update_ac_factor;
+  P.value_passes = 3;
+  n->scratch_eng.seed(init_seed ^ 0x5c7a7c45eedull);
+  if (cfg->vnn_from_scratch && (rc = dalloc(h, &n->d_fresh, (size_t)G * h->net[1].nd.stride()))) return bail(rc);
   P.update_delta_neg = cfg->update_delta_neg ? 1 : 0;
   P.gae = cfg->gae ? 1 : 0;
   P.lambda = (float)cfg->lambda;
@@ -291,7 +310,24 @@ extern "C" int ddrl_nfac_max_trajectory(ddrl_pop_t *h) {
 static int launch_critic(ddrl_pop *h, NfacHost *n, int chunks, int maxlen, int &steps) {
   const ddrl_nfac_config &c = n->cfg;
   for (int fit = 0; fit < c.number_fitted_iteration; ++fit) {
-    HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));
+    if (c.vnn_from_scratch) {
+      // :266-284: the targets come from the OLD critic's V(s'); then a new net (weights ~N(0, 0.01^2), MLP.hpp:936-944,
+      // new solver: zero moments, iter 0) whose V(s) enters the lambda return (:315)
+      n->P.value_passes = 2;
+      HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));
+      std::normal_distribution<double> nd01(0.0, 0.01);
+      std::vector<double> flat((size_t)h->G * h->net[1].nd.np);
+      for (auto &x : flat) x = nd01(n->scratch_eng);
+      int rc = upload_flat(h, h->net[1].nd, n->d_fresh, flat.data());
+      if (rc) return rc;
+      HIPCHK(nfac_reinit_launch(&n->P, n->d_fresh, h->stream));
+      n->P.value_passes = 1;
+      HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));
+      n->P.value_passes = 3;
+      steps = 0;
+    } else {
+      HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));
+    }
     HIPCHK(nfac_scan_launch(&n->P, 0, maxlen, h->stream));
     for (int it = 0; it < c.stoch_iter_critic; ++it) {
       HIPCHK(nfac_grad_launch(&n->P, 0, chunks, h->stream));
@@ -381,6 +417,12 @@ int ddrl_nfac_checkpoint(ddrl_pop *h, Ckpt &c) {
   if (c.writing)
     for (size_t g = 0; g < G; ++g) { flat.push_back((int)n->h_ends[g].size()); flat.insert(flat.end(), n->h_ends[g].begin(), n->h_ends[g].end()); }
   if ((rc = c.vec("nfac.ends", flat))) return rc;
+  if (n->cfg.vnn_from_scratch) {                          // the stream the next re-created critics are drawn from
+    std::vector<char> es;
+    if (c.writing) { std::ostringstream os; os << n->scratch_eng; const std::string t = os.str(); es.assign(t.begin(), t.end()); }
+    if ((rc = c.vec("nfac.scratch_eng", es))) return rc;
+    if (!c.writing) { std::istringstream is(std::string(es.begin(), es.end())); is >> n->scratch_eng; }
+  }
   if (!c.writing) {
     size_t p = 0;
     for (size_t g = 0; g < G; ++g) {

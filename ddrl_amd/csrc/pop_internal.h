@@ -159,6 +159,9 @@ struct NfacParams {
   int G, S, A, maxT, rowlen, maxchunks;
   int ldh;                        // LDS row stride reserved for hidden activations
   int inverting, update_delta_neg, gae;
+  int corrected;                  // agent.corrected_update_ac: actor diff = -(target - pi) * corr_factor, no inverting gradient
+  float corr_factor;
+  int value_passes;               // nfac_values_kernel: bit 0 = V(s), bit 1 = V(s')
   float lambda;
   float beta1, beta2, omb1, omb2, eps, fisher_beta;
   double dbeta1, dbeta2;

@@ -50,6 +50,7 @@ class NfacConfigC(C.Structure):
         ("ewc", C.c_double), ("ewc_decay", C.c_double), ("ewc_fisher_beta", C.c_double),
         ("ewc_best_param_method", C.c_int), ("ewc_for_critic", C.c_int),
         ("device", C.c_int),
+        ("vnn_from_scratch", C.c_int), ("corrected_update_ac", C.c_int), ("corrected_update_ac_factor", C.c_double),
     ]
 
 

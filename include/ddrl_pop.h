@@ -312,6 +312,12 @@ typedef struct {
   double ewc, ewc_decay, ewc_fisher_beta;
   int    ewc_best_param_method, ewc_for_critic;
   int    device;
+  /* agent.vnn_from_scratch (mandatory key, OfflineCaclaAg.hpp:129): every fitted iteration of update_critic starts
+   * from a NEW critic -- weights ~N(0, 0.01^2), fresh Adam state, iter = 0, no EWC (:281-284); refused together
+   * with EWC on the critic.  agent.corrected_update_ac (+ _factor, :164-173): the actor's output diff is
+   * -(target - pi) * factor, without the inverting-gradient scaling (:550-563). */
+  int    vnn_from_scratch, corrected_update_ac;
+  double corrected_update_ac_factor;
 } ddrl_nfac_config;
 
 int ddrl_nfac_config_default(ddrl_nfac_config *cfg);

@@ -3,7 +3,7 @@
  *
  * fp64 restatement of NFAC(lambda)-V, OfflineCaclaAg::update_critic and ::end_episode
  * (agent/cacla/include/OfflineCaclaAg.hpp:242-401, 403-595), batch_norm == 0 branches only
- * (BatchNorm is outside this round's scope), corrected_update_ac == false.
+ * (BatchNorm is outside this round's scope).
  * No reference test pins this arithmetic: parity unpinned beyond the MLP known-answer tests.
  */
 #include "ora.h"
@@ -13,6 +13,7 @@
 struct ora_nfac {
   ora_nfac_cfg c;
   ora_mlp *ann, *vnn;
+  double *fresh; int n_fresh, next_fresh;
 };
 
 ora_nfac *ora_nfac_create(const ora_nfac_cfg *c) {
@@ -39,7 +40,15 @@ ora_nfac *ora_nfac_create(const ora_nfac_cfg *c) {
 
 void ora_nfac_free(ora_nfac *d) {
   if (!d) return;
-  ora_mlp_free(d->ann); ora_mlp_free(d->vnn); free(d);
+  ora_mlp_free(d->ann); ora_mlp_free(d->vnn); free(d->fresh); free(d);
+}
+
+void ora_nfac_set_fresh(ora_nfac *d, const double *w, int n) {
+  const int np = ora_mlp_nparams(d->vnn);
+  free(d->fresh);
+  d->fresh = (double *)malloc(sizeof(double) * (size_t)np * (n > 0 ? n : 1));
+  memcpy(d->fresh, w, sizeof(double) * (size_t)np * n);
+  d->n_fresh = n; d->next_fresh = 0;
 }
 
 ora_mlp *ora_nfac_net(ora_nfac *d, int which) { return which == 0 ? d->ann : d->vnn; }
@@ -73,6 +82,13 @@ static void update_critic(ora_nfac *d, int T, const double *s, const double *s2,
       double target = r[li];
       if (!goal[li]) target += c->gamma * nextV[li];
       v_target[li] = target;
+    }
+    if (c->vnn_from_scratch && d->next_fresh < d->n_fresh) {                 /* :281-284: a new net, new solver, no EWC */
+      const int np = ora_mlp_nparams(d->vnn);
+      double *zero = (double *)calloc(np, sizeof(double));
+      ora_mlp_set_weights(d->vnn, d->fresh + (size_t)np * d->next_fresh++);
+      ora_mlp_set_adam(d->vnn, zero, zero, 0);
+      free(zero);
     }
     if (c->lambda < 0.) {
       ora_mlp_learn_batch(d->vnn, s, v_target, T, c->stoch_iter_critic);     /* :285-286 */
@@ -132,7 +148,8 @@ int ora_nfac_update(ora_nfac *d, int T, const double *s, const double *pure_a, c
           else {
             double x = actions[i] - ac_out[i];
             ac_diff[i] = -x;
-            if (c->inverting_gradient) {
+            if (c->corrected_update_ac) ac_diff[i] = -x * c->corrected_update_ac_factor;   /* :561-563 */
+            else if (c->inverting_gradient) {
               const double min_ = -1.0, max_ = 1.0;
               if (ac_diff[i] < 0) ac_diff[i] *= (max_ - ac_out[i]) / (max_ - min_);
               else if (ac_diff[i] > 0) ac_diff[i] *= (ac_out[i] - min_) / (max_ - min_);

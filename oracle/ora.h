@@ -112,11 +112,17 @@ typedef struct {
   double gamma, lambda, alpha_a, alpha_v;
   double ewc, ewc_decay, ewc_fisher_beta;
   int ewc_for_critic, ewc_best_method;
+  int vnn_from_scratch;              /* OfflineCaclaAg.hpp:129,281-284 */
+  int corrected_update_ac;           /* :164-173, 550-563 */
+  double corrected_update_ac_factor;
 } ora_nfac_cfg;
 typedef struct ora_nfac ora_nfac;
 ora_nfac *ora_nfac_create(const ora_nfac_cfg *c);
 void   ora_nfac_free(ora_nfac *d);
 ora_mlp *ora_nfac_net(ora_nfac *d, int which);   /* 0 ann 1 vnn */
+/* vnn_from_scratch: the weights the re-created critics start from, n vectors of the critic's parameter count,
+ * consumed one per fitted iteration (the reference draws them from Caffe's generator; the caller supplies them) */
+void   ora_nfac_set_fresh(ora_nfac *d, const double *w, int n);
 /* the learning branch of OfflineCaclaAg::end_episode (OfflineCaclaAg.hpp:423-594) on a trajectory
  * set of T rows; ends[n_ends] = trajectory_end_points. Returns n (positively advantaged rows). */
 int    ora_nfac_update(ora_nfac *d, int T, const double *s, const double *pure_a, const double *a,

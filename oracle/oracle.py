@@ -49,6 +49,7 @@ class NfacCfg(C.Structure):
         ("gamma", C.c_double), ("lambda_", C.c_double), ("alpha_a", C.c_double), ("alpha_v", C.c_double),
         ("ewc", C.c_double), ("ewc_decay", C.c_double), ("ewc_fisher_beta", C.c_double),
         ("ewc_for_critic", C.c_int), ("ewc_best_method", C.c_int),
+        ("vnn_from_scratch", C.c_int), ("corrected_update_ac", C.c_int), ("corrected_update_ac_factor", C.c_double),
     ]
 
 
@@ -120,6 +121,7 @@ def lib():
     L.ora_nfac_net.restype = vp
     L.ora_nfac_net.argtypes = [vp, C.c_int]
     L.ora_nfac_update.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int, vp]
+    L.ora_nfac_set_fresh.argtypes = [vp, _dp, C.c_int]
     L.ora_cmaes_create.restype = vp
     L.ora_cmaes_create.argtypes = [C.c_int, _dp, _dp, C.c_long, C.c_int]
     L.ora_cmaes_free.argtypes = [vp]
@@ -343,7 +345,8 @@ class Nfac:
                  update_delta_neg=False, update_critic_first=True, gae=True, inverting_gradient=False,
                  number_fitted_iteration=10, stoch_iter_actor=10, stoch_iter_critic=10,
                  gamma=0.99, lambda_=0.9, alpha_a=1e-4, alpha_v=1e-3,
-                 ewc=-1.0, ewc_decay=-1.0, ewc_fisher_beta=0.999, ewc_for_critic=0, ewc_best_method=0):
+                 ewc=-1.0, ewc_decay=-1.0, ewc_fisher_beta=0.999, ewc_for_critic=0, ewc_best_method=0,
+                 vnn_from_scratch=False, corrected_update_ac=False, corrected_update_ac_factor=1.0):
         c = NfacCfg()
         c.S, c.A = S, A
         c.n_hidden_a = len(hidden_a); _fill_hidden(c.hidden_a, hidden_a)
@@ -355,6 +358,8 @@ class Nfac:
         c.gamma, c.lambda_, c.alpha_a, c.alpha_v = gamma, lambda_, alpha_a, alpha_v
         c.ewc, c.ewc_decay, c.ewc_fisher_beta = ewc, ewc_decay, ewc_fisher_beta
         c.ewc_for_critic, c.ewc_best_method = ewc_for_critic, ewc_best_method
+        c.vnn_from_scratch, c.corrected_update_ac = int(vnn_from_scratch), int(corrected_update_ac)
+        c.corrected_update_ac_factor = corrected_update_ac_factor
         self.S, self.A = S, A
         self.h = lib().ora_nfac_create(C.byref(c))
         da = [S] + list(hidden_a) + [A]
@@ -370,6 +375,10 @@ class Nfac:
     def ann(self): return self.nets[0]
     @property
     def vnn(self): return self.nets[1]
+
+    def set_fresh(self, w):
+        w = np.ascontiguousarray(w, np.float64).reshape(-1, self.vnn.np)
+        lib().ora_nfac_set_fresh(self.h, w, w.shape[0])
 
     def update(self, s, pure_a, a, s2, r, goal, ends):
         T = len(r)

@@ -106,6 +106,27 @@ def test_td3_ini_keys(tmp_path):
             ddrl_amd.Td3Population(ddrl_amd.DdpgConfig(n_agents=2, td3=1, inverting_grad=0))
 
 
+def test_nfac_ini_keys(tmp_path):
+    """OfflineCaclaAg::_unique_invoke (OfflineCaclaAg.hpp:124-179): vnn_from_scratch is a mandatory key, corrected_update_ac
+    (+ _factor) optional; both change the algorithm (:281-284, 561-563) and are carried in the config, not dropped."""
+    import ddrl_amd
+    base = ("[agent]\ngamma=0.99\ndecision_each=1\nnoise=0.1\ngaussian_policy=1\nhidden_unit_v=8:6\nhidden_unit_a=8\n"
+            "update_delta_neg=false\nupdate_critic_first=true\nnumber_fitted_iteration=2\nstoch_iter_actor=3\n"
+            "stoch_iter_critic=4\nbatch_norm_actor=0\nbatch_norm_critic=0\nactor_output_layer_type=2\nhidden_layer_type=1\n"
+            "alpha_a=0.001\nalpha_v=0.002\nlambda=0.9\nmomentum=0\ngae=true\n")
+    p = tmp_path / "nfac.ini"
+    p.write_text(base + "vnn_from_scratch=true\ncorrected_update_ac=true\ncorrected_update_ac_factor=0.25\n")
+    c = ddrl_amd.NfacConfig.from_ini(str(p), n_agents=2, nb_sensors=4, nb_motors=1)
+    assert c.get("vnn_from_scratch") == 1 and c.get("corrected_update_ac") == 1 and c.get("corrected_update_ac_factor") == 0.25
+    assert c.get("hidden_unit_v") == [8, 6] and c.get("stoch_iter_critic") == 4 and c.get("gae") == 1
+    p.write_text(base + "vnn_from_scratch=false\n")
+    c = ddrl_amd.NfacConfig.from_ini(str(p), n_agents=2, nb_sensors=4, nb_motors=1)
+    assert c.get("vnn_from_scratch") == 0 and c.get("corrected_update_ac") == 0 and c.get("corrected_update_ac_factor") == 1.0
+    p.write_text(base)
+    with pytest.raises(ddrl_amd.DdrlError, match="vnn_from_scratch"):
+        ddrl_amd.NfacConfig.from_ini(str(p), n_agents=2, nb_sensors=4, nb_motors=1)
+
+
 def test_no_cpu_fallback():
     if HAVE_GPU:
         pytest.skip("GPU present")

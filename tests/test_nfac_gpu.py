@@ -52,7 +52,9 @@ def make_pair(ora, G, S, A, hidden_a, hidden_v, maxT, seed=0, wscale=0.1, **kw):
                stoch_iter_actor=cfg.get("stoch_iter_actor"), stoch_iter_critic=cfg.get("stoch_iter_critic"),
                lambda_=cfg.get("lambda"), ewc=cfg.get("ewc"), ewc_decay=cfg.get("ewc_decay"),
                ewc_fisher_beta=cfg.get("ewc_fisher_beta"), ewc_for_critic=cfg.get("ewc_for_critic"),
-               ewc_best_method=cfg.get("ewc_best_param_method"))
+               ewc_best_method=cfg.get("ewc_best_param_method"),
+               vnn_from_scratch=cfg.get("vnn_from_scratch"), corrected_update_ac=cfg.get("corrected_update_ac"),
+               corrected_update_ac_factor=cfg.get("corrected_update_ac_factor"))
     agents = []
     for g in range(G):
         ag = ora.Nfac(S, A, hidden_a, hidden_v, gamma=float(np.float32(gamma[g])),
@@ -118,6 +120,8 @@ CASES = {
     "small_td0": (4, 1, (20,), (50, 7), dict(lambda_=-1.0, gae=0, update_delta_neg=1)),
     "ragged3": (18, 6, (33, 17, 9), (40, 21), dict(lambda_=0.6, gae=0, inverting_gradient=1, hidden_layer_type=2)),
     "momentum1": (18, 6, (32, 32), (32, 32), dict(lambda_=0.95, gae=1, momentum=1, actor_output_layer_type=0, inverting_gradient=1)),
+    # agent.corrected_update_ac (OfflineCaclaAg.hpp:164-173, 561-563): diff = -(target - pi) * factor, the inverting gradient is skipped
+    "corrected": (18, 6, (32, 32), (32, 32), dict(lambda_=0.9, gae=1, corrected_update_ac=1, corrected_update_ac_factor=0.35, inverting_gradient=1)),
 }
 
 
@@ -291,3 +295,56 @@ def test_ewc_lifecycle(ora):
             co = ag.nets[net].ewc_cost()
             assert abs(cost[g] - co) <= 1e-4 * max(abs(co), 1e-12), (net, g, cost[g], co)
             assert co > 0
+
+
+def test_vnn_from_scratch(ora):
+    """agent.vnn_from_scratch (OfflineCaclaAg.hpp:129, 281-284): every fitted iteration of update_critic replaces the
+    critic by a new net -- weights ~N(0, 0.01^2), zero Adam moments, iter 0 -- AFTER the targets were taken from the
+    old one.  The fresh weights come from the handle's own stream (Caffe's cannot be matched): they are harvested
+    from a twin handle that takes no step after the re-creation, then handed to the oracle (set_fresh)."""
+    S, A, ha, hv = 18, 6, (32, 32), (32, 32)
+    G, maxT, sic = 4, 200, 3
+    kw = dict(update_critic_first=1, lambda_=0.9, gae=1, number_fitted_iteration=1, stoch_iter_actor=1, vnn_from_scratch=1)
+    twin, _, _ = make_pair(ora, G, S, A, ha, hv, maxT, seed=8, stoch_iter_critic=0, **kw)
+    pop, agents, lrs = make_pair(ora, G, S, A, ha, hv, maxT, seed=8, stoch_iter_critic=sic, **kw)
+    lens = [200, 77, 0, 130]
+    mask = np.array([1, 1, 1, 0], np.uint8)
+    load_trajs(twin, np.random.RandomState(4), lens, S, A)
+    trajs = load_trajs(pop, np.random.RandomState(4), lens, S, A)
+    wv_before = pop.weights(1).copy()
+    twin.update(mask=mask)
+    fresh = twin.weights(1)
+    m, v, it = twin.adam(1)
+    for g in (0, 1):                                   # re-created: new draw, new solver
+        assert abs(np.std(fresh[g]) - 0.01) < 0.002 and abs(np.mean(fresh[g])) < 0.002
+        assert not m[g].any() and not v[g].any() and it[g] == 0
+    for g in (2, 3):                                   # no trajectory / masked: the critic stays
+        assert np.array_equal(fresh[g], wv_before[g])
+    sync_oracle(pop, agents)
+    pop.update(mask=mask)
+    last = pop.last()
+    w, (m, v, it) = pop.weights(1), pop.adam(1)
+    for g in (0, 1):
+        agents[g].set_fresh(fresh[g])
+        rows, ends = trajs[g]
+        n, deltas = oracle_update(agents[g], rows, ends, S, A)
+        assert int(it[g]) == sic == agents[g].vnn.iter()
+        wo = agents[g].vnn.weights()
+        assert close_frac(w[g], wo, 1e-4, 0.99, 1e-2), g            # sic free-running Adam steps from the same fresh net
+        assert rel_err(last["deltas"][g, :lens[g]], deltas) <= 1e-3, g
+        assert int(last["n_pos"][g]) == n
+    for g in (2, 3):
+        assert np.array_equal(w[g], wv_before[g]) and it[g] == 0
+    # three fitted iterations: three re-creations, the last one's solver counts the steps
+    pop3, _, _ = make_pair(ora, G, S, A, ha, hv, maxT, seed=8, stoch_iter_critic=2, **dict(kw, number_fitted_iteration=3))
+    load_trajs(pop3, np.random.RandomState(4), lens, S, A)
+    pop3.update()
+    assert list(pop3.adam(1)[2]) == [2, 2, 0, 2] and np.isfinite(pop3.weights(1)).all()
+
+
+def test_from_scratch_refused_with_critic_ewc():
+    import ddrl_amd
+    from ddrl_amd.lib import DdrlError
+    cfg = ddrl_amd.NfacConfig(n_agents=1, nb_sensors=4, nb_motors=1, vnn_from_scratch=1, ewc=10.0, ewc_for_critic=1)
+    with pytest.raises(DdrlError, match="vnn_from_scratch"):
+        ddrl_amd.NfacPopulation(cfg, init_seed=1)
