@@ -11,7 +11,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <unistd.h>
 #include "../../include/ddrl_pop.h"
 #include "host_util.h"
 
@@ -21,13 +23,22 @@ struct Ckpt {
   std::string path;
   hipStream_t st = nullptr;
   std::vector<char> stage;
-  ~Ckpt() { if (f) fclose(f); }
+  std::string tmp;
+  uint64_t file_bytes = 0;
+  ~Ckpt() { if (f) { fclose(f); if (writing) remove(tmp.c_str()); } }     // an abandoned write leaves no partial file
 
   int open(const char *p, bool w) {
     if (!p) return ddrl_fail(DDRL_EINVAL, "NULL path");
     path = p; writing = w;
-    f = fopen(p, w ? "wb" : "rb");
-    if (!f) return ddrl_fail(DDRL_EIO, "cannot open %s", p);
+    // written next to the target and renamed over it once complete and on disk (finish): a pre-emption in the middle
+    // of a multi-GB write -- the event run files exist for -- leaves the previous file intact
+    tmp = path + ".tmp";
+    f = fopen(w ? tmp.c_str() : p, w ? "wb" : "rb");
+    if (!f) return ddrl_fail(DDRL_EIO, "cannot open %s", w ? tmp.c_str() : p);
+    if (!w) {                                                            // bounds every length a record may claim
+      if (fseek(f, 0, SEEK_END) == 0) { const long e = ftell(f); file_bytes = e > 0 ? (uint64_t)e : 0; }
+      rewind(f);
+    }
     char magic[8] = {'D', 'D', 'R', 'L', 'R', 'U', 'N', '1'};
     if (w) { if (fwrite(magic, 1, 8, f) != 8) return ddrl_fail(DDRL_EIO, "write to %s failed", p); return DDRL_OK; }
     char got[8];
@@ -73,7 +84,7 @@ struct Ckpt {
     int rc = head(tag, &nb, false);
     if (rc) return rc;
     if (!writing) {
-      if (nb % sizeof(T)) return ddrl_fail(DDRL_EIO, "%s: record '%s' has a broken length", path.c_str(), tag);
+      if (nb % sizeof(T) || nb > file_bytes) return ddrl_fail(DDRL_EIO, "%s: record '%s' has a broken length", path.c_str(), tag);
       v.resize(nb / sizeof(T));
     }
     return payload(v.data(), nb);
@@ -113,10 +124,12 @@ struct Ckpt {
     return DDRL_OK;
   }
   int finish() {
-    if (writing && (fflush(f) != 0 || ferror(f))) return ddrl_fail(DDRL_EIO, "write to %s failed", path.c_str());
+    if (writing && (fflush(f) != 0 || ferror(f) || fsync(fileno(f)) != 0)) return ddrl_fail(DDRL_EIO, "write to %s failed", tmp.c_str());
     int rc = DDRL_OK;
-    if (fclose(f) != 0 && writing) rc = ddrl_fail(DDRL_EIO, "close of %s failed", path.c_str());
+    if (fclose(f) != 0 && writing) rc = ddrl_fail(DDRL_EIO, "close of %s failed", tmp.c_str());
     f = nullptr;
+    if (writing && rc == DDRL_OK && rename(tmp.c_str(), path.c_str()) != 0) rc = ddrl_fail(DDRL_EIO, "cannot rename %s to %s", tmp.c_str(), path.c_str());
+    if (writing && rc != DDRL_OK) remove(tmp.c_str());
     return rc;
   }
 };

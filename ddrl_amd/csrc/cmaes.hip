@@ -327,6 +327,15 @@ static int cm_alloc(ddrl_cmaes *h, T **p, size_t n) {
   return DDRL_OK;
 }
 
+// ATTRIBUTION.  rnd_start / rnd_uniform / rnd_gauss and eig::tridiag / eig::ql below follow, operation for operation,
+// cmaes_random_Start / _Uniform / _Gauss and Householder2 / QLalgo2 of N. Hansen's c-cmaes (agent/cmaes/src/cmaes.c:
+// 2421-2482 and 1986-2261 in the reference tree; (c) 1996, 2003, 2007 Nikolaus Hansen, dual-licensed Apache-2.0 /
+// LGPL-2.1+, cmaes.c:14-26), the latter two being c-cmaes' port of JAMA's tred2 / tql2 (public domain, NIST / MathWorks,
+// from EISPACK).  A bit-identical z stream and eigen schedule require the same operations in the same order, so
+// these ~170 lines are a restatement by necessity (parity mode); the throughput mode uses this library's own device
+// routines instead.
+
+
 // cmaes_random_Start / _Uniform / _Gauss (cmaes.c:2421-2482)
 static void rnd_start(ddrl_cmaes *t, unsigned long inseed) {
   t->flgstored = 0;

@@ -67,8 +67,10 @@ ddpg_update_kernel(const DdpgParams P) {
     __shared__ int go;
     if (threadIdx.x == 0) {
       int ok = 0;
-      for (long long spin = 0; spin < (1ll << 22); ++spin) {              // ~ seconds: never reached in a healthy run
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz: bounded by TIME (4 s), never reached in a healthy run
+      while (true) {
         if (__hip_atomic_load(P.upd_done + agent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= u) { ok = 1; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) break;
         __builtin_amdgcn_s_sleep(8);
       }
       if (!ok) __hip_atomic_store(P.upd_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -123,6 +125,7 @@ static hipError_t launch_ewc(const DdpgParams *P, size_t lds, hipStream_t st) {
   const bool ea = P->sa.fisher != nullptr, eq = P->sq.fisher != nullptr;
   if (ea && eq) return launch_t<NA, NQ, true, true>(P, lds, st);
   if (ea) return launch_t<NA, NQ, true, false>(P, lds, st);
+  if (eq) return hipErrorInvalidValue;      // EWC on the critic alone: no ini produces it (DODevMLP.hpp:714-720 needs ewc >= 0), and no instantiation exists
   return launch_t<NA, NQ, false, false>(P, lds, st);
 }
 

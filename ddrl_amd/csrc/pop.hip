@@ -360,7 +360,7 @@ extern "C" int ddrl_pop_load_flat_dev(ddrl_pop_t *h, int net, const float *d_fla
   const uint8_t *dmask;
   if ((rc = upload_mask(h, mask, &dmask))) return rc;
   HIPCHK(load_flat_launch(&t->nd, net_weights(h, net), d_flat, ld, dmask, h->G, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -388,16 +388,7 @@ extern "C" int ddrl_pop_shape(ddrl_pop_t *h, int *kind, int *n_agents, int *nb_s
 
 extern "C" int ddrl_pop_sync(ddrl_pop_t *h) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (h->algo == 0 && h->P.upd_error) {        // raised by a multi-update launch whose ordering wait expired
-    int err = 0;
-    HIPCHK(hipMemcpy(&err, h->P.upd_error, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) {
-      HIPCHK(hipMemset(h->P.upd_error, 0, sizeof(int)));
-      return ddrl_fail(DDRL_ESTATE, "a multi-update launch gave up waiting for an agent's previous update: some updates were skipped");
-    }
-  }
-  return DDRL_OK;
+  return ddrl_pop_wait(h);
 }
 
 extern "C" int ddrl_pop_set_hyper(ddrl_pop_t *h, const char *key, const double *v) {
@@ -459,7 +450,7 @@ extern "C" int ddrl_pop_get_adam(ddrl_pop_t *h, int net, double *m, double *v, i
   if (v && (rc = download_flat(h, t->nd, t->st.v, v))) return rc;
   if (iter) {
     HIPCHK(hipMemcpyAsync(iter, t->st.iter, h->G * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
   }
   return DDRL_OK;
 }
@@ -473,7 +464,7 @@ extern "C" int ddrl_pop_set_adam(ddrl_pop_t *h, int net, const double *m, const 
   if (v && (rc = upload_flat(h, t->nd, t->st.v, v))) return rc;
   if (iter) {
     HIPCHK(hipMemcpyAsync(t->st.iter, iter, h->G * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
   }
   return DDRL_OK;
 }
@@ -486,7 +477,7 @@ extern "C" int ddrl_pop_seed_replay(ddrl_pop_t *h, const uint32_t *seeds) {
   uint32_t *d_seeds = (uint32_t *)h->d_idx;   // G words of scratch (d_idx holds G*B >= G ints)
   HIPCHK(hipMemcpyAsync(d_seeds, seeds, h->G * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(mt_seed_launch(h->d_mt, h->d_mtpos, d_seeds, h->G, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -506,7 +497,7 @@ extern "C" int ddrl_pop_replay_append(ddrl_pop_t *h, const float *s, const float
   HIPCHK(hipMemcpyAsync(h->d_goal, goal, (size_t)G, hipMemcpyHostToDevice, h->stream));
   HIPCHK(replay_append_launch(h->d_rep, h->d_len, h->d_head, G, h->cfg.replay_memory, h->rowlen, S, A,
                               h->d_s, h->d_a, h->d_r, h->d_s2, h->d_goal, dmask, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
+  DDRL_WAIT(h);   // host buffers may be reused by the caller
   for (int g = 0; g < G; ++g) {
     if (mask && !mask[g]) continue;
     if (h->h_len[g] >= h->cfg.replay_memory) h->h_head[g] = (h->h_head[g] + 1) % h->cfg.replay_memory;
@@ -530,7 +521,7 @@ extern "C" int ddrl_pop_replay_load(ddrl_pop_t *h, int agent, int n, const float
   h->h_head[agent] = 0;
   HIPCHK(hipMemcpyAsync(h->d_len + agent, &h->h_len[agent], sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_head + agent, &h->h_head[agent], sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -544,7 +535,7 @@ extern "C" int ddrl_pop_replay_clear(ddrl_pop_t *h, const uint8_t *mask) {
     if (!mask || mask[g]) { h->h_len[g] = 0; h->h_head[g] = 0; }
   HIPCHK(hipMemcpyAsync(h->d_len, h->h_len.data(), h->G * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_head, h->h_head.data(), h->G * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -554,7 +545,7 @@ extern "C" int ddrl_pop_replay_len(ddrl_pop_t *h, int32_t *len) {
   int rc = set_device(h);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(len, h->d_len, h->G * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -575,7 +566,7 @@ extern "C" int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions
   HIPCHK(hipMemcpyAsync(h->d_s, states, (size_t)G * S * 4, hipMemcpyHostToDevice, h->stream));
   if ((rc = ddrl_pop_infer_dev(h, h->d_s, h->d_act))) return rc;
   HIPCHK(hipMemcpyAsync(actions, h->d_act, (size_t)G * A * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -634,7 +625,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   }
   const int per_launch = fused ? n : 1;
   if ((size_t)G * B * per_launch > h->idx_cap) {       // grows once; the old buffer stays on the handle's free list
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
     if ((rc = dalloc(h, &h->d_idx, (size_t)G * B * per_launch))) return rc;
     h->idx_cap = (size_t)G * B * per_launch;
     h->P.idx = h->d_idx;
@@ -688,6 +679,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
     if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   }
   h->P.pair = 0;
+  if (per_launch > 1) h->multi_pending = true;
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
 }
@@ -774,7 +766,7 @@ extern "C" int ddrl_pop_td3_seed_noise(ddrl_pop_t *h, const uint64_t *seeds) {
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(h->d_nseed, seeds, h->G * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemsetAsync(h->d_ncount, 0, h->G * sizeof(uint32_t), h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -786,7 +778,7 @@ extern "C" int ddrl_pop_td3_last(ddrl_pop_t *h, float *loss2, float *noise) {
   const size_t G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;
   if (loss2) HIPCHK(hipMemcpyAsync(loss2, h->d_loss2, G * 4, hipMemcpyDeviceToHost, h->stream));
   if (noise) HIPCHK(hipMemcpyAsync(noise, h->d_noise, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -810,7 +802,7 @@ extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, floa
   if (loss) HIPCHK(hipMemcpyAsync(loss, h->d_loss, G * 4, hipMemcpyDeviceToHost, h->stream));
   if (qt) HIPCHK(hipMemcpyAsync(qt, h->d_qt, G * B * 4, hipMemcpyDeviceToHost, h->stream));
   if (dact) HIPCHK(hipMemcpyAsync(dact, h->d_dact, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return DDRL_OK;
 }
 
@@ -846,7 +838,7 @@ extern "C" int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *act
   if (h->gates_on) {
     HIPCHK(hipMemcpyAsync(sg.data(), h->d_sgate, sg.size() * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(ag.data(), h->d_agate, ag.size() * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
   }
   if (state_gate) for (size_t i = 0; i < G * S; ++i) state_gate[i] = sg[i];
   if (action_gate) for (size_t i = 0; i < G * A; ++i) action_gate[i] = ag[i];
@@ -879,7 +871,7 @@ extern "C" int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score, co
     if (!any) continue;
     if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
     HIPCHK(snapshot_launch(t.st.best, t.st.w, t.nd.stride(), h->d_flag, h->G, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
   }
   return DDRL_OK;
 }
@@ -890,7 +882,7 @@ static int ewc_setup_one(ddrl_pop *h, TrainNet &t, const uint8_t *mask) {
   std::vector<uint8_t> flag(h->G, 0);
   std::vector<float> nbr(h->G);
   HIPCHK(hipMemcpyAsync(nbr.data(), t.st.fisher_nbr, h->G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   bool any = false;
   for (int g = 0; g < h->G; ++g) {
     if (mask && !mask[g]) continue;
@@ -908,7 +900,7 @@ static int ewc_setup_one(ddrl_pop *h, TrainNet &t, const uint8_t *mask) {
   if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
   HIPCHK(ewc_setup_launch(t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride(),
                           h->d_flag, h->G, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   return refresh_ewc_coef(h, t);
 }
 
@@ -952,7 +944,7 @@ extern "C" int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost) {
   HIPCHK(ewc_cost_launch(t.st.w, t.st.wstar, t.st.fhat, t.nd.stride(), h->d_cost, h->G, h->stream));
   std::vector<float> c(h->G);
   HIPCHK(hipMemcpyAsync(c.data(), h->d_cost, h->G * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   for (int g = 0; g < h->G; ++g) {
     if (!t.ewc.live[g]) continue;
     double r = (double)c[g] * h->cfg.ewc / (double)t.nd.np;                // DODevMLP.hpp:679-683
@@ -974,7 +966,7 @@ extern "C" int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *
   if (fisher_nbr) {
     std::vector<float> f(h->G);
     HIPCHK(hipMemcpyAsync(f.data(), t.st.fisher_nbr, h->G * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
     for (int g = 0; g < h->G; ++g) fisher_nbr[g] = f[g];
   }
   if (decay_mult) for (int g = 0; g < h->G; ++g) decay_mult[g] = t.ewc.decay_mult[g];
@@ -1050,7 +1042,7 @@ static int pop_run_file(ddrl_pop *h, const char *path, bool save) {
   if (!h || !path) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   int rc = set_device(h);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   Ckpt c;
   if ((rc = c.open(path, save)) || (rc = ddrl_pop_checkpoint(h, c))) return rc;
   return c.finish();
@@ -1069,7 +1061,7 @@ extern "C" int ddrl_pop_profile_read(ddrl_pop_t *h, double *kernel_ms, int *laun
   if (!h || !kernel_ms || !launches) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   int rc = set_device(h);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  DDRL_WAIT(h);
   double tot = 0.;
   for (size_t i = 0; i < h->ev_used; ++i) {
     float ms = 0.f;
@@ -1090,7 +1082,7 @@ extern "C" int ddrl_pop_debug_stamps(ddrl_pop_t *h, int enable, long long *out) 
   h->P.stamps = enable ? h->d_stamps : nullptr;
   if (out) {
     HIPCHK(hipMemcpyAsync(out, h->d_stamps, (size_t)h->G * 16 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
   }
   return DDRL_OK;
 }
@@ -1108,7 +1100,7 @@ extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
     int rc = set_device(h);
     if (rc) return rc;
     if ((rc = chunk_buffers(h))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
     return DDRL_OK;
   }
   if (std::string(key) == "force_wide") {        // the layer-by-layer kernels on nets the fused kernel would take
@@ -1120,7 +1112,7 @@ extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
     int rc = set_device(h);
     if (rc) return rc;
     if ((rc = chunk_buffers(h))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    DDRL_WAIT(h);
     return DDRL_OK;
   }
   return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);

@@ -78,6 +78,7 @@ struct ddrl_pop {
   // measurement
   bool profiling = false;
   int force_generic = 0;
+  bool multi_pending = false;   // a multi-update launch was issued since the error word was last read (ddrl_pop_wait)
   int resident_mode = 0;      // 1: small nets keep an agent's whole state in LDS for a multi-update launch (ddpg_update_resident_kernel)
   int pair_mode = 1;          // 0: never the two-agents-per-workgroup kernel, 1: for launches of >= DDRL_PAIR_MIN_UPD updates, 2: whenever it fits
   bool force_chunked = false;
@@ -240,5 +241,26 @@ static bool bad_net(ddrl_pop *h, int net) {
   return net < 0 || net > DDRL_NET_CRITIC2_TARGET || (net > DDRL_NET_CRITIC_TARGET && h->nnets < 3) ||
          (h->algo == 1 && net > DDRL_NET_CRITIC) || (h->algo == 2 && net != DDRL_NET_ACTOR);
 }
+// Waits for the handle's stream.  After a multi-update launch (ddrl_pop_ddpg_update_n) it also looks at the launch's error
+// word: a workgroup that gave up waiting for its agent's previous update (kernels_ddpg.hip) or a team barrier that
+// expired (kernels_ddpg_pair.hip) left updates undone, and NO reader of the state (weights, Adam state, diagnostics,
+// run files) may then return it as if it were healthy.
+static inline int ddrl_pop_wait(ddrl_pop *h) {
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+  if (h->multi_pending && h->P.upd_error) {
+    h->multi_pending = false;
+    int err = 0;
+    e = hipMemcpy(&err, h->P.upd_error, sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return ddrl_fail(DDRL_EHIP, "hipMemcpy: %s", hipGetErrorString(e));
+    if (err) {
+      (void)hipMemset(h->P.upd_error, 0, sizeof(int));
+      return ddrl_fail(DDRL_ESTATE, "a multi-update launch gave up waiting for an agent's previous update: some updates were skipped");
+    }
+  }
+  return DDRL_OK;
+}
+#define DDRL_WAIT(h) do { int rc_w_ = ddrl_pop_wait(h); if (rc_w_) return rc_w_; } while (0)
+
 #define DDPG_ONLY(h) do { if ((h)->algo != 0) return ddrl_fail(DDRL_ESTATE, "%s: DDPG populations only", __func__); } while (0)
 

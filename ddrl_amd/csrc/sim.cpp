@@ -7,6 +7,7 @@
 //
 // Host code only.  The environments themselves (ODE worlds in the reference) are the caller's: a table of
 // C callbacks, one environment instance per agent, each driven by one thread at a time.
+#include <unistd.h>
 #include "../../include/ddrl_pop.h"
 #include "host_util.h"
 #include "pool.h"
@@ -188,10 +189,14 @@ extern "C" int ddrl_sim_run_episode(ddrl_sim_t *s, int learning, long lepisode, 
   if (s->can_continue && learning && lepisode % s->continue_save_each == 0 && lepisode > 0) {          // :196-200
     const std::string run = s->out_dir + "/continue.ddrl_pop", simu = s->out_dir + "/continue.simu.data";
     if ((rc = ddrl_agents_save_run(s->agents, run.c_str()))) return rc;
-    FILE *f = fopen(simu.c_str(), "w");
-    if (!f) return ddrl_fail(DDRL_EIO, "cannot write %s", simu.c_str());
-    fprintf(f, "%ld\n", lepisode + 1);
-    fclose(f);
+    // the run file went to disk under a temporary name and was renamed over the old one (ckpt.h); the episode marker
+    // follows the same way, so at any instant both files are complete (a stop between the two renames resumes the
+    // new state under the old episode number: episodes are repeated in the logs, nothing is lost)
+    const std::string tmp = simu + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "w");
+    if (!f) return ddrl_fail(DDRL_EIO, "cannot write %s", tmp.c_str());
+    const bool okw = fprintf(f, "%ld\n", lepisode + 1) > 0 && fflush(f) == 0 && fsync(fileno(f)) == 0;
+    if (fclose(f) != 0 || !okw || rename(tmp.c_str(), simu.c_str()) != 0) { remove(tmp.c_str()); return ddrl_fail(DDRL_EIO, "cannot write %s", simu.c_str()); }
   }
   return DDRL_OK;
 }

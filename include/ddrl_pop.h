@@ -55,7 +55,7 @@ typedef struct {
   int    nb_sensors, nb_motors;    /* DeepQNAg ctor (DeepQNAg.hpp:95-98) */
   int    n_hidden_a; int hidden_unit_a[DDRL_MAX_HIDDEN];   /* agent.hidden_unit_a */
   int    n_hidden_q; int hidden_unit_q[DDRL_MAX_HIDDEN];   /* agent.hidden_unit_q */
-  int    mini_batch_size;          /* agent.mini_batch_size (<= 64, multiple of 16 in this round) */
+  int    mini_batch_size;          /* agent.mini_batch_size (1..4096; up to 64 rows run as one fused launch) */
   int    replay_memory;            /* agent.replay_memory */
   int    inverting_grad;           /* agent.inverting_grad */
   int    force_more_update;        /* agent.force_more_update */
