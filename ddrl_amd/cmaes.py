@@ -62,6 +62,23 @@ class Cmaes:
         _l.check(self._L.ddrl_cmaes_population_dev(self._h, C.byref(p), C.byref(ld)))
         return p.value, ld.value
 
+    def sample_dev(self):
+        """cmaes_SamplePopulation without the host copy: returns (device pointer of X [lambda x ld] fp32, ld)"""
+        _l.check(self._L.ddrl_cmaes_sample(self._h))
+        return self.population_dev()
+
+    def population_torch(self):
+        """the sampled population as a torch view [lambda x N] (fp32) of the library's device buffer: no copy"""
+        import torch
+        ptr, ld = self.population_dev()
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"data": (ptr, False), "shape": (self.lam, self.N), "typestr": "<f4",
+                                      "strides": (4 * ld, 4), "version": 2}
+        return torch.as_tensor(v, device="cuda")
+
     def update(self, fitness):
         f = np.ascontiguousarray(fitness, np.float64)
         if f.shape != (self.lam,):

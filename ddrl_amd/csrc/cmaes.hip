@@ -6,7 +6,8 @@
 // Device (fp32 matrices, fp64 vectors/scalars):
 //   cmaes_gemm_nt       X = m + sigma * DZ * B^T            (cmaes.c:645-652)        fp32 MFMA GEMM
 //   cmaes_rank_kernel   Sorted_index                        (cmaes.c:2989-3000)      exact LDS sort
-//   cmaes_vec_kernel    mean, BDz, ps, hsig, pc, sigma      (cmaes.c:826-898, 952)   one workgroup
+//   cmaes_mean/btv/bv/path_kernel   mean, BDz, ps, hsig, pc, sigma   (cmaes.c:826-898, 952)   fp64, all CUs
+//   cmaes_jacobi_*      C = B diag(D^2) B^T, one-sided Jacobi in fp64 (throughput mode; cmaes.c:1885-2261 is the host path)
 //   cmaes_pack_y        y_k = sqrt(w_k) (x_{k:lambda} - m_old) / sigma  (cmaes.c:985-989)
 //   cmaes_gemm_nt       C <- a C + c1 pc pc^T + cmu Y Y^T   (cmaes.c:979-991)        fp32 MFMA GEMM
 // Host (fp64): parameter defaults, the reference's LCG + Box-Muller stream (sequential by
@@ -16,8 +17,6 @@
 #include "pop_internal.h"
 #include "host_util.h"
 #include "ckpt.h"
-
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -152,7 +151,14 @@ cmaes_rank_kernel(const double *__restrict__ f, int n, int npow2, int *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// The O(N mu + N^2) vector part of cmaes_UpdateDistribution (cmaes.c:825-898, 952), one workgroup.
+// The O(N mu + N^2) vector part of cmaes_UpdateDistribution (cmaes.c:825-898, 952) in fp64, spread over the chip
+// (it was one 1024-thread workgroup: 1.04 ms = 85 % of a generation's GPU time at lambda = 4096):
+//   cmaes_mean_kernel   flat-fitness sigma bump, best-ever, xmean = sum_k w_k x_{k:lambda}, BDz       ceil(N / 64) workgroups
+//   cmaes_btv_kernel    z = D^-1 B^T BDz: column sums of B, coalesced across columns                    ceil(N / 64) workgroups
+//   cmaes_bv_kernel     ps = (1 - cs) ps + sqrt(cs (2 - cs)) B z: one wave per row of B                 ceil(N / 4) workgroups
+//   cmaes_path_kernel   |ps|^2, hsig, pc, sigma                                                          one workgroup
+// Every sum runs in a fixed order (no atomics): results do not depend on scheduling.
+// sc[SC_SIGMA] is read by the first three and rewritten by the last one only; the bumped value travels in sc[SC_SIGMA_C].
 // ---------------------------------------------------------------------------------------------
 struct CmaesVecArgs {
   int N, ldx, ldn, lambda, mu;
@@ -164,64 +170,95 @@ struct CmaesVecArgs {
   double *xmean, *xold, *ps, *pc, *BDz, *tmp, *D, *sc, *xbest;
 };
 
-__global__ void __launch_bounds__(1024)
-cmaes_vec_kernel(const CmaesVecArgs a) {
-  __shared__ double red[1024];
-  const int tid = threadIdx.x, N = a.N;
-  // flat fitness: sigma *= exp(0.2 + cs/damps)   (cmaes.c:826-831)
-  if (tid == 0) {
-    double sigma = a.sc[SC_SIGMA];
-    if (a.fit[a.index[0]] == a.fit[a.index[a.lambda / 2]]) sigma *= exp(0.2 + a.cs / a.damps);
-    a.sc[SC_SIGMA] = sigma;
-    a.sc[SC_SIGMA_C] = sigma;                      // Adapt_C2 uses sigma before its final update
-  }
-  // best-ever solution (cmaes.c:834-841)
+// sigma after the flat-fitness bump (cmaes.c:826-831): every workgroup derives it from the same inputs
+__device__ __forceinline__ double cmaes_sigma_bumped(const CmaesVecArgs &a) {
+  double sigma = a.sc[SC_SIGMA];
+  if (a.fit[a.index[0]] == a.fit[a.index[a.lambda / 2]]) sigma *= exp(0.2 + a.cs / a.damps);
+  return sigma;
+}
+
+__global__ void __launch_bounds__(256)
+cmaes_mean_kernel(const CmaesVecArgs a) {
+  __shared__ double part[4][64];
+  const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+  const int i = blockIdx.x * 64 + c, N = a.N;
+  const double sigma = cmaes_sigma_bumped(a);
   const int ibest = a.index[0];
-  const bool newbest = a.sc[SC_FBEST] > a.fit[ibest] || a.gen == 1.;
-  __syncthreads();
-  if (newbest) {
-    for (int i = tid; i < N; i += 1024) a.xbest[i] = (double)a.X[(size_t)ibest * a.ldx + i];
-    if (tid == 0) a.sc[SC_FBEST] = a.fit[ibest];
+  const bool newbest = a.sc[SC_FBEST] > a.fit[ibest] || a.gen == 1.;       // best-ever solution (cmaes.c:834-841)
+  // xmean_i = sum_k w_k x_{k:lambda, i}: rows k = q, q + 4, ... per quarter, the quarters added in order
+  double m = 0.;
+  if (i < N) {
+    // eight rows in flight per thread (the rows are scattered by index: a dependent chain of single loads is latency-bound)
+    double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    int k = q;
+    for (; k + 28 < a.mu; k += 32) {
+      float x[8]; double w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { x[u] = a.X[(size_t)a.index[k + 4 * u] * a.ldx + i]; w[u] = a.weights[k + 4 * u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += w[u] * (double)x[u];
+    }
+    for (; k < a.mu; k += 4) acc[0] += a.weights[k] * (double)a.X[(size_t)a.index[k] * a.ldx + i];
+    m = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
-  const double sigma = a.sc[SC_SIGMA];
-  // xmean = sum_k w_k x_{k:lambda};  BDz = sqrt(mueff) (xmean - xold) / sigma   (cmaes.c:846-852)
-  for (int i = tid; i < N; i += 1024) {
+  part[q][c] = m;
+  __syncthreads();
+  if (q == 0 && i < N) {
+    m = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
     const double old = a.xmean[i];
-    double m = 0.;
-    for (int k = 0; k < a.mu; ++k) m += a.weights[k] * (double)a.X[(size_t)a.index[k] * a.ldx + i];
     a.xold[i] = old;
     a.xmean[i] = m;
-    a.BDz[i] = sqrt(a.mueff) * (m - old) / sigma;
+    a.BDz[i] = sqrt(a.mueff) * (m - old) / sigma;                            // cmaes.c:846-852
+    if (newbest) a.xbest[i] = (double)a.X[(size_t)ibest * a.ldx + i];
   }
+  if (blockIdx.x == 0 && tid == 0) a.sc[SC_SIGMA_C] = sigma;                 // Adapt_C2 uses sigma before its final update
+}
+
+// z = D^-1 B^T BDz   (cmaes.c:855-862)
+__global__ void __launch_bounds__(256)
+cmaes_btv_kernel(const CmaesVecArgs a) {
+  __shared__ double part[4][64];
+  const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+  const int i = blockIdx.x * 64 + c, N = a.N;
+  double s = 0.;
+  if (i < N)
+    for (int j = q; j < N; j += 4) s += (double)a.B[(size_t)j * a.ldn + i] * a.BDz[j];
+  part[q][c] = s;
   __syncthreads();
-  // z = D^-1 B^T BDz   (cmaes.c:855-862)
-  for (int i = tid; i < N; i += 1024) {
-    double s = 0.;
-    for (int j = 0; j < N; ++j) s += (double)a.B[(size_t)j * a.ldn + i] * a.BDz[j];
-    a.tmp[i] = s / a.D[i];
-  }
-  __syncthreads();
-  // ps = (1 - cs) ps + sqrt(cs (2 - cs)) B z   (cmaes.c:878-886)
+  if (q == 0 && i < N) a.tmp[i] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / a.D[i];
+}
+
+// ps = (1 - cs) ps + sqrt(cs (2 - cs)) B z   (cmaes.c:878-886): one wave per row, lanes stride the row
+__global__ void __launch_bounds__(256)
+cmaes_bv_kernel(const CmaesVecArgs a) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), N = a.N;
+  if (i >= N) return;
+  double s = 0.;
+  for (int j = lane; j < N; j += 64) s += (double)a.B[(size_t)i * a.ldn + j] * a.tmp[j];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) a.ps[i] = (1. - a.cs) * a.ps[i] + sqrt(a.cs * (2. - a.cs)) * s;
+}
+
+// |ps|^2, hsig, pc, sigma   (cmaes.c:893-898, 952); the best value travels here too (the mean kernel's workgroups still read it)
+__global__ void __launch_bounds__(1024)
+cmaes_path_kernel(const CmaesVecArgs a) {
+  __shared__ double red[1024];
+  const int tid = threadIdx.x, N = a.N;
   double part = 0.;
-  for (int i = tid; i < N; i += 1024) {
-    double s = 0.;
-    for (int j = 0; j < N; ++j) s += (double)a.B[(size_t)i * a.ldn + j] * a.tmp[j];
-    const double p = (1. - a.cs) * a.ps[i] + sqrt(a.cs * (2. - a.cs)) * s;
-    a.ps[i] = p;
-    part += p * p;
-  }
+  for (int i = tid; i < N; i += 1024) { const double p = a.ps[i]; part += p * p; }
   red[tid] = part;
   __syncthreads();
   for (int s = 512; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
   const double psxps = red[0];
-  // hsig, pc   (cmaes.c:893-898)
   const double hsig = (sqrt(psxps) / sqrt(1. - pow(1. - a.cs, 2. * a.gen)) / a.chiN < 1.4 + 2. / (N + 1)) ? 1. : 0.;
   for (int i = tid; i < N; i += 1024)
     a.pc[i] = (1. - a.ccumcov) * a.pc[i] + hsig * sqrt(a.ccumcov * (2. - a.ccumcov)) * a.BDz[i];
   if (tid == 0) {
+    const int ibest = a.index[0];
+    if (a.sc[SC_FBEST] > a.fit[ibest] || a.gen == 1.) a.sc[SC_FBEST] = a.fit[ibest];
     a.sc[SC_PSXPS] = psxps;
     a.sc[SC_HSIG] = hsig;
-    a.sc[SC_SIGMA] = sigma * exp(((sqrt(psxps) / a.chiN) - 1.) * a.cs / a.damps);   // cmaes.c:952
+    a.sc[SC_SIGMA] = a.sc[SC_SIGMA_C] * exp(((sqrt(psxps) / a.chiN) - 1.) * a.cs / a.damps);   // cmaes.c:952
   }
 }
 
@@ -296,8 +333,12 @@ struct ddrl_cmaes {
   // schedule
   double gen = 0, countevals = 0, genOfEigensysUpdate = 0;
   int state = 0, eigen_uptodate = 1;
-  int device_eigen = 0;                  // throughput mode: rocSOLVER dsyevd on the GPU instead of the host JAMA routines
-  double *d_A = nullptr, *d_ev = nullptr, *d_E = nullptr;
+  int device_eigen = 0;                  // throughput mode: one-sided Jacobi on the GPU instead of the host JAMA routines
+  int eigen_sweeps = 0;                  // sweeps the last device eigendecomposition took
+  hipGraphExec_t sweep_graph = nullptr;  // one Jacobi sweep (N - 1 rounds) as a captured graph
+  bool sweep_graph_failed = false;
+  int eig_warm = 0;                      // d_W holds the previous eigenvectors: the next decomposition starts from them
+  double *d_A = nullptr, *d_ev = nullptr, *d_W = nullptr, *d_Cs = nullptr;
   int *d_info = nullptr;
   int device_rng = 0;                    // throughput mode: Philox on the device instead of c-cmaes' stream
   unsigned int rng_seed = 0, rng_draw = 0;
@@ -509,64 +550,172 @@ static int upload_BD(ddrl_cmaes *h) {
   return DDRL_OK;
 }
 
-// rocSOLVER / rocBLAS entry points, bound lazily: only the "device_eigen" throughput option needs them
-struct RocSolver {
-  void *blas = nullptr, *solver = nullptr, *handle = nullptr;
-  int (*create)(void **) = nullptr;
-  int (*set_stream)(void *, hipStream_t) = nullptr;
-  int (*dsyevd)(void *, int, int, int, double *, int, double *, double *, int *) = nullptr;
-};
-static RocSolver *rocsolver_get() {
-  static RocSolver rs;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    rs.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!rs.blas) rs.blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    rs.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!rs.solver) rs.solver = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-    if (rs.blas && rs.solver) {
-      rs.create = (int (*)(void **))dlsym(rs.blas, "rocblas_create_handle");
-      rs.set_stream = (int (*)(void *, hipStream_t))dlsym(rs.blas, "rocblas_set_stream");
-      rs.dsyevd = (int (*)(void *, int, int, int, double *, int, double *, double *, int *))dlsym(rs.solver, "rocsolver_dsyevd");
-      if (rs.create && rs.set_stream && rs.dsyevd && rs.create(&rs.handle) != 0) rs.handle = nullptr;
-    }
-  }
-  return rs.handle ? &rs : nullptr;
-}
-
-// lower triangle of the fp32 C -> full fp64 matrix for the solver
-__global__ void cmaes_c_to_f64(const float *__restrict__ C, int ldn, int N, double *__restrict__ A) {
+// ---------------------------------------------------------------------------------------------
+// "device_eigen" (throughput mode): C = B diag(D^2) B^T on the GPU in fp64 by the parallel cyclic ONE-SIDED JACOBI
+// method (Hestenes), this library's own routine -- no vendor solver.
+// G starts as C (rows g_i), W as the identity.  A Givens rotation in the (p, q) plane is applied to the rows of both,
+// chosen so that g_p . g_q becomes 0; a round rotates N / 2 disjoint row pairs at once (round-robin tournament
+// order, one workgroup per pair), N - 1 rounds make a sweep.  When all rows of G = W C are mutually orthogonal, W C^2 W^T
+// is diagonal: the rows of W are the eigenvectors and lambda_i = w_i C w_i^T = g_i . w_i.  Convergence is quadratic;
+// it stops when a whole sweep found |g_p . g_q| <= 1e-9 |g_p| |g_q| for every pair (the eigenvalue error is second
+// order in that, and B is stored in fp32): 6-9 sweeps, each replayed as ONE captured HIP graph of N - 1 rounds.
+// Any orthonormal eigenbasis samples the same distribution; this one differs from c-cmaes' Householder / QL basis in
+// signs, order and inside (near-)degenerate eigenspaces, so the mode is for throughput, not for seed-for-seed
+// comparison (parity mode keeps the host routines above).  Eigenvalues agree with them to ~1e-13 relative
+// (tests/test_cmaes_gpu.py).
+// ---------------------------------------------------------------------------------------------
+// lower triangle of the fp32 C -> full fp64 G; W = I
+__global__ void cmaes_jacobi_init(const float *__restrict__ C, int ldn, int N, double *__restrict__ G, double *__restrict__ W) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (j >= N || i >= N) return;
-  A[(size_t)i * N + j] = (double)(j <= i ? C[(size_t)i * ldn + j] : C[(size_t)j * ldn + i]);
+  G[(size_t)i * N + j] = (double)(j <= i ? C[(size_t)i * ldn + j] : C[(size_t)j * ldn + i]);
+  if (W) W[(size_t)i * N + j] = i == j ? 1. : 0.;
 }
 
-static int upload_BD(ddrl_cmaes *h);
+__device__ __forceinline__ double block_sum256(double v, double *red, int tid) {   // all threads get the sum
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ void block_sum256x3(double &a, double &b, double &c, double *red /* [12] */, int tid) {
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+  if ((tid & 63) == 0) { red[tid >> 6] = a; red[4 + (tid >> 6)] = b; red[8 + (tid >> 6)] = c; }
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  b = (red[4] + red[5]) + (red[6] + red[7]);
+  c = (red[8] + red[9]) + (red[10] + red[11]);
+}
 
-// "device_eigen": C = B diag(D^2) B^T by rocsolver_dsyevd in fp64 on the GPU.  Any orthonormal
-// eigenbasis samples the same distribution; the basis differs from c-cmaes' Householder/QL one in
-// signs and inside (near-)degenerate eigenspaces, so this mode is for throughput, not for
-// seed-for-seed comparison.
+// warm start: G = W Cs with W the previous generation's eigenvectors (rows) -- C moved by O(ccov) since, so the rows of G
+// are nearly orthogonal already and the iteration needs 2-4 sweeps instead of 9-11 from W = I
+__global__ void __launch_bounds__(256)
+cmaes_jacobi_warm(const double *__restrict__ W, const double *__restrict__ Cs, int N, double *__restrict__ G) {
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= N) return;
+  const double *w = W + (size_t)i * N;
+  double s0 = 0., s1 = 0.;
+  int k = 0;
+  for (; k + 1 < N; k += 2) { s0 += w[k] * Cs[(size_t)k * N + j]; s1 += w[k + 1] * Cs[(size_t)(k + 1) * N + j]; }
+  if (k < N) s0 += w[k] * Cs[(size_t)k * N + j];
+  G[(size_t)i * N + j] = s0 + s1;
+}
+
+// round `step` of a sweep over n2 = N rounded up to even players: workgroup b rotates the pair it is dealt
+__global__ void __launch_bounds__(256)
+cmaes_jacobi_round(double *__restrict__ G, double *__restrict__ W, int N, int n2, int step, int *__restrict__ rotated) {
+  __shared__ double red[12];
+  const int tid = threadIdx.x, b = blockIdx.x, m = n2 - 1;
+  int p, q;
+  if (b == 0) { p = m; q = step; }
+  else { p = (step + b) % m; q = (step - b + m) % m; }
+  if (p >= N || q >= N) return;                     // the bye of an odd N
+  if (p > q) { const int t = p; p = q; q = t; }
+  double *gp = G + (size_t)p * N, *gq = G + (size_t)q * N, *wp = W + (size_t)p * N, *wq = W + (size_t)q * N;
+  // up to JR elements of each of the four rows per thread stay in registers from the dot products to the rotation:
+  // one memory round trip per round instead of two (rows longer than 256 JR take the tail from memory again)
+  constexpr int JR = 3;
+  double xg[JR], yg[JR], xw[JR], yw[JR];
+  double al = 0., be = 0., ga = 0.;
+#pragma unroll
+  for (int r = 0; r < JR; ++r) {
+    const int i = tid + 256 * r;
+    const bool in = i < N;
+    xg[r] = in ? gp[i] : 0.; yg[r] = in ? gq[i] : 0.; xw[r] = in ? wp[i] : 0.; yw[r] = in ? wq[i] : 0.;
+  }
+#pragma unroll
+  for (int r = 0; r < JR; ++r) { al += xg[r] * xg[r]; be += yg[r] * yg[r]; ga += xg[r] * yg[r]; }
+  for (int i = tid + 256 * JR; i < N; i += 256) { const double x = gp[i], y = gq[i]; al += x * x; be += y * y; ga += x * y; }
+  block_sum256x3(al, be, ga, red, tid);
+  if (fabs(ga) <= 1e-9 * sqrt(al * be)) return;     // uniform: orthogonal enough (eigenvalue error is second order: 1e-18)
+  const double zeta = (be - al) / (2. * ga);
+  const double t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+  const double c = 1. / sqrt(1. + t * t), sn = c * t;
+#pragma unroll
+  for (int r = 0; r < JR; ++r) {
+    const int i = tid + 256 * r;
+    if (i < N) {
+      gp[i] = c * xg[r] - sn * yg[r]; gq[i] = sn * xg[r] + c * yg[r];
+      wp[i] = c * xw[r] - sn * yw[r]; wq[i] = sn * xw[r] + c * yw[r];
+    }
+  }
+  for (int i = tid + 256 * JR; i < N; i += 256) {
+    const double x = gp[i], y = gq[i];
+    gp[i] = c * x - sn * y; gq[i] = sn * x + c * y;
+    const double u = wp[i], v = wq[i];
+    wp[i] = c * u - sn * v; wq[i] = sn * u + c * v;
+  }
+  if (tid == 0) atomicAdd(rotated, 1);
+}
+
+// lambda_i = g_i . w_i, D_i = sqrt(max(lambda_i, 0)), B[:, i] = w_i (fp32, the sampling GEMM's operand)
+__global__ void __launch_bounds__(256)
+cmaes_jacobi_finish(const double *__restrict__ G, const double *__restrict__ W, int N, int ldn, double *__restrict__ ev,
+                    double *__restrict__ D, float *__restrict__ B) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, i = blockIdx.x;
+  double l = 0.;
+  for (int j = tid; j < N; j += 256) {
+    const double w = W[(size_t)i * N + j];
+    l += G[(size_t)i * N + j] * w;
+    B[(size_t)j * ldn + i] = (float)w;
+  }
+  l = block_sum256(l, red, tid);
+  if (tid == 0) { ev[i] = l; D[i] = sqrt(l > 0. ? l : 0.); }
+}
+
 static int device_eigen(ddrl_cmaes *h) {
-  RocSolver *rs = rocsolver_get();
-  if (!rs) return ddrl_fail(DDRL_ESTATE, "device_eigen: librocsolver / librocblas could not be loaded");
-  const int N = h->N;
-  hipLaunchKernelGGL(cmaes_c_to_f64, dim3((N + 63) / 64, N), dim3(64), 0, h->stream, h->d_C, h->ldn, N, h->d_A);
+  const int N = h->N, n2 = (N + 1) / 2 * 2;
+  if (h->eig_warm) {       // Cs = C in fp64 (d_Cs), G = W_prev Cs; W keeps the previous eigenvectors
+    hipLaunchKernelGGL(cmaes_jacobi_init, dim3((N + 63) / 64, N), dim3(64), 0, h->stream, h->d_C, h->ldn, N, h->d_Cs, (double *)nullptr);
+    hipLaunchKernelGGL(cmaes_jacobi_warm, dim3((N + 255) / 256, N), dim3(256), 0, h->stream, h->d_W, h->d_Cs, N, h->d_A);
+  } else {
+    hipLaunchKernelGGL(cmaes_jacobi_init, dim3((N + 63) / 64, N), dim3(64), 0, h->stream, h->d_C, h->ldn, N, h->d_A, h->d_W);
+  }
   HIPCHK(hipGetLastError());
-  if (rs->set_stream(rs->handle, h->stream) != 0) return ddrl_fail(DDRL_EHIP, "rocblas_set_stream failed");
-  // column-major lower == row-major upper of the same symmetric matrix: either triangle is complete here
-  if (rs->dsyevd(rs->handle, 211 /* rocblas_evect_original */, 122 /* rocblas_fill_lower */, N, h->d_A, N, h->d_ev, h->d_E, h->d_info) != 0)
-    return ddrl_fail(DDRL_EHIP, "rocsolver_dsyevd failed");
-  std::vector<double> A((size_t)N * N);
-  int info = 0;
-  HIPCHK(hipMemcpyAsync(A.data(), h->d_A, A.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  int sweeps = 0;
+  if (N > 1) {
+    // one sweep = n2 - 1 dependent launches: captured once as a HIP graph and replayed (the rounds are launch-bound)
+    if (!h->sweep_graph && !h->sweep_graph_failed) {
+      hipGraph_t g = nullptr;
+      bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        for (int step = 0; step < n2 - 1; ++step)
+          hipLaunchKernelGGL(cmaes_jacobi_round, dim3(n2 / 2), dim3(256), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
+        ok = hipStreamEndCapture(h->stream, &g) == hipSuccess && g;
+      }
+      if (ok) ok = hipGraphInstantiate(&h->sweep_graph, g, nullptr, nullptr, 0) == hipSuccess;
+      if (g) (void)hipGraphDestroy(g);
+      if (!ok) { h->sweep_graph = nullptr; h->sweep_graph_failed = true; (void)hipGetLastError(); }
+    }
+    for (; sweeps < 60; ++sweeps) {
+      HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+      if (h->sweep_graph) {
+        HIPCHK(hipGraphLaunch(h->sweep_graph, h->stream));
+      } else {
+        for (int step = 0; step < n2 - 1; ++step)
+          hipLaunchKernelGGL(cmaes_jacobi_round, dim3(n2 / 2), dim3(256), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
+      }
+      HIPCHK(hipGetLastError());
+      int rotated = 0;
+      HIPCHK(hipMemcpyAsync(&rotated, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (rotated == 0) break;
+    }
+    if (sweeps == 60) return ddrl_fail(DDRL_EHIP, "device_eigen: the Jacobi iteration did not converge in 60 sweeps");
+  }
+  h->eigen_sweeps = sweeps;
+  h->eig_warm = 1;
+  hipLaunchKernelGGL(cmaes_jacobi_finish, dim3(N), dim3(256), 0, h->stream, h->d_A, h->d_W, N, h->ldn, h->d_ev, h->d_D, h->d_B);
+  HIPCHK(hipGetLastError());
+  // host mirrors (TestForTermination, ddrl_cmaes_get_vec): eigenvalues now, B = W^T
+  std::vector<double> Wh((size_t)N * N);
+  HIPCHK(hipMemcpyAsync(Wh.data(), h->d_W, Wh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(h->D.data(), h->d_ev, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (info != 0) return ddrl_fail(DDRL_EHIP, "rocsolver_dsyevd did not converge (info = %d)", info);
   for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) h->B[(size_t)i * N + j] = A[(size_t)j * N + i];     // eigenvector j = column j (column-major)
+    for (int j = 0; j < N; ++j) h->B[(size_t)j * N + i] = Wh[(size_t)i * N + j];
   return DDRL_OK;
 }
 
@@ -583,7 +732,7 @@ static int update_eigensystem(ddrl_cmaes *h) {
     for (int i = 0; i < N; ++i) h->D[i] = std::sqrt(std::max(h->D[i], 0.));
     h->eigen_uptodate = 1;
     h->genOfEigensysUpdate = h->gen;
-    return upload_BD(h);
+    return DDRL_OK;                         // d_B and d_D were written by cmaes_jacobi_finish
   }
   std::vector<float> Cf((size_t)N * h->ldn);
   HIPCHK(hipMemcpyAsync(Cf.data(), h->d_C, Cf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -704,6 +853,7 @@ extern "C" int ddrl_cmaes_destroy(ddrl_cmaes_t *h) {
   if (!h) return DDRL_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->sweep_graph) (void)hipGraphExecDestroy(h->sweep_graph);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -893,7 +1043,10 @@ extern "C" int ddrl_cmaes_update_dev(ddrl_cmaes_t *h, const double *d_fitness) {
   a.X = h->d_X; a.B = h->d_B; a.fit = h->d_fit; a.index = h->d_index; a.weights = h->d_w;
   a.xmean = h->d_xmean; a.xold = h->d_xold; a.ps = h->d_ps; a.pc = h->d_pc; a.BDz = h->d_BDz; a.tmp = h->d_tmp;
   a.D = h->d_D; a.sc = h->d_sc; a.xbest = h->d_xbest;
-  hipLaunchKernelGGL(cmaes_vec_kernel, dim3(1), dim3(1024), 0, h->stream, a);
+  hipLaunchKernelGGL(cmaes_mean_kernel, dim3((N + 63) / 64), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(cmaes_btv_kernel, dim3((N + 63) / 64), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(cmaes_bv_kernel, dim3((N + 3) / 4), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(cmaes_path_kernel, dim3(1), dim3(1024), 0, h->stream, a);
   HIPCHK(hipGetLastError());
   // Adapt_C2 (cmaes.c:963-1001), diagonalCov == 0
   if (h->ccov != 0.) {
@@ -930,7 +1083,7 @@ extern "C" int ddrl_cmaes_get(ddrl_cmaes_t *h, const char *key, double *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return DDRL_OK;
   }
-  if (k == "gen") *out = h->gen; else if (k == "lambda") *out = h->lambda; else if (k == "mu") *out = h->mu;
+  if (k == "eigen_sweeps") *out = h->eigen_sweeps; else if (k == "gen") *out = h->gen; else if (k == "lambda") *out = h->lambda; else if (k == "mu") *out = h->mu;
   else if (k == "N" || k == "dim") *out = h->N; else if (k == "mueff") *out = h->mueff; else if (k == "cs") *out = h->cs;
   else if (k == "damps") *out = h->damps; else if (k == "ccumcov") *out = h->ccumcov; else if (k == "ccov") *out = h->ccov;
   else if (k == "mucov") *out = h->mucov; else if (k == "chiN") *out = h->chiN; else if (k == "modulo") *out = h->modulo;
@@ -1028,7 +1181,7 @@ extern "C" int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int m
 
 // options (throughput modes; same algorithm, not seed-for-seed comparable with c-cmaes):
 //   "device_rng" (0/1): draw z on the device (Philox) instead of evaluating c-cmaes' sequential
-//   generator on the host;  "device_eigen" (0/1): eigendecomposition by rocSOLVER on the GPU.
+//   generator on the host;  "device_eigen" (0/1): eigendecomposition by one-sided Jacobi on the GPU (device_eigen above).
 extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value) {
   if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (std::string(key) == "device_rng") { h->device_rng = value != 0; return DDRL_OK; }
@@ -1037,10 +1190,11 @@ extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value
       HIPCHK(hipSetDevice(h->device));
       int rc;
       if ((rc = cm_alloc(h, &h->d_A, (size_t)h->N * h->N)) || (rc = cm_alloc(h, &h->d_ev, h->N)) ||
-          (rc = cm_alloc(h, &h->d_E, h->N)) || (rc = cm_alloc(h, &h->d_info, 1))) return rc;
-      if (!rocsolver_get()) return ddrl_fail(DDRL_ESTATE, "device_eigen: librocsolver / librocblas could not be loaded");
+          (rc = cm_alloc(h, &h->d_W, (size_t)h->N * h->N)) || (rc = cm_alloc(h, &h->d_Cs, (size_t)h->N * h->N)) ||
+          (rc = cm_alloc(h, &h->d_info, 1))) return rc;
     }
     h->device_eigen = value != 0;
+    h->eig_warm = 0;
     return DDRL_OK;
   }
   return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);
@@ -1072,6 +1226,13 @@ int ddrl_cmaes_checkpoint(ddrl_cmaes_t *h, Ckpt &c) {
       (rc = c.dev("cmaes.Ddev", h->d_D, N * sizeof(double))) || (rc = c.dev("cmaes.sc", h->d_sc, SC_N * sizeof(double))) ||
       (rc = c.dev("cmaes.xbest", h->d_xbest, N * sizeof(double))) || (rc = c.dev("cmaes.index", h->d_index, L * sizeof(int))))
     return rc;
+  // throughput mode: the eigenvectors the next Jacobi iteration starts from (a cold start would give another, equally
+  // valid basis: the continuation would no longer be bit-identical)
+  int dev_eig = h->device_eigen;
+  if ((rc = c.same("cmaes.device_eigen", &dev_eig, sizeof(dev_eig)))) return rc;
+  if (h->device_eigen) {
+    if ((rc = c.val("cmaes.eig_warm", h->eig_warm)) || (rc = c.dev("cmaes.W", h->d_W, N * N * sizeof(double)))) return rc;
+  }
   return DDRL_OK;
 }
 

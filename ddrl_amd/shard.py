@@ -51,6 +51,28 @@ def all_gather_fitness(local_fitness, n_total, rank, world, device=None):
     return np.concatenate([out[r, : sizes[r]] for r in range(world)])
 
 
+def all_gather_fitness_torch(local, n_total, rank, world):
+    """The same collective on torch tensors that stay where they are: `local` (fp64, this rank's block, on the GPU under
+    RCCL / on the CPU under gloo) -> tensor [n_total] on the same device, ready for ddrl_cmaes_update_dev.  One
+    all_gather_into_tensor of world x max-block doubles (32 KiB at lambda = 4096: latency-bound over xGMI)."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = block_range(n_total, rank, world)
+    if tuple(local.shape) != (hi - lo,) or local.dtype != torch.float64:
+        raise ValueError("rank %d owns %d individuals (fp64), got %s %s" % (rank, hi - lo, tuple(local.shape), local.dtype))
+    if world == 1:
+        return local.contiguous()
+    sizes = block_sizes(n_total, world)
+    m = max(sizes)
+    buf = torch.zeros(m, dtype=torch.float64, device=local.device)
+    buf[: hi - lo] = local
+    out = torch.empty(world * m, dtype=torch.float64, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    if min(sizes) == m:
+        return out
+    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
+
+
 class ShardedCmaes:
     """CMA-ES generation loop over `world` ranks: every rank holds the same distribution (same seed ->
     same z stream -> same population), evaluates its block of individuals, and the update runs on the
@@ -67,3 +89,20 @@ class ShardedCmaes:
         fit = all_gather_fitness(local, self.lam, self.rank, self.world, self.device)
         self.es.update(fit)
         return fit
+
+    def generation_dev(self, fitness_fn_torch):
+        """The same generation without leaving the device: the population is a torch view of the library's buffer,
+        `fitness_fn_torch(X_block)` returns this rank's fitness as an fp64 tensor on that device, the all-gather runs
+        on device buffers (RCCL), and the gathered tensor's address goes straight into ddrl_cmaes_update_dev.
+        Every rank samples the whole population (2 lambda N^2 flops: 28 us at lambda = 4096, N = 631); what is
+        sharded is the evaluation."""
+        import torch
+        self.es.sample_dev()
+        X = self.es.population_torch()
+        local = fitness_fn_torch(X[self.lo:self.hi]).to(torch.float64)
+        fit = all_gather_fitness_torch(local, self.lam, self.rank, self.world)
+        if fit.is_cuda:
+            torch.cuda.current_stream().synchronize()       # the library works on its own stream
+        self.es.update_dev(fit.data_ptr())
+        return fit
+

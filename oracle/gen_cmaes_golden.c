@@ -122,6 +122,7 @@ int main(int argc, char **argv) {
   else if (!strcmp(c, "n40")) run_case(40, 64, 3, 30, f_rosen, "rosen", 0, 0.2, 0.3, 0);
   else if (!strcmp(c, "n151")) run_case(151, 50, 2, 12, f_elli, "elli", 0, 0.1, 0.5, 0);
   else if (!strcmp(c, "n151_big")) run_case(151, 4096, 5, 3, f_sphere, "sphere", 0, 0.1, 0.5, 0);
+  else if (!strcmp(c, "n631_big")) run_case(631, 4096, 5, 3, f_sphere, "sphere", 0, 0.1, 0.5, 0);   /* the half-cheetah actor */
   else if (!strcmp(c, "term_flat")) run_case(4, 6, 2, 30, f_const, "const", 1, 0.5, 0.5, 1);
   else if (!strcmp(c, "term_noeffect")) run_case(4, 6, 4, 8, f_sphere, "sphere", 1, 144115188075855872.0 /* 2^57: means exactly representable in fp32 */, 1.0, 1);
   else if (!strcmp(c, "term_sphere")) run_case(5, 8, 1, 20, f_sphere, "sphere", 1, 0.5, 0.5, 1);

@@ -43,7 +43,7 @@ def make(ora, g):
     return dev, ref, x0
 
 
-@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big"])
+@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big", "n631_big"])
 def test_parameters_bit_exact(ora, name):
     g = load(name)
     dev, _, _ = make(ora, g)
@@ -70,7 +70,7 @@ def test_rank_tie_rule(ora):
 
 # term_noeffect (|mean| ~ 1e17) is left to the CPU oracle test: with steps below one ulp of the mean the
 # update amplifies last-bit differences of the fp64 mean (FMA contraction) by 1e16; no fp32/fp64 bar applies.
-@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big", "term_flat", "term_sphere"])
+@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big", "n631_big", "term_flat", "term_sphere"])
 def test_generations_teacher_forced(ora, name):
     g = load(name)
     N, lam = g["N"], g["lambda"]
@@ -193,8 +193,9 @@ def test_device_rng_throughput_mode():
 
 
 def test_device_eigen_throughput_mode():
-    """"device_eigen": rocSOLVER eigendecomposition on the GPU; the basis need not equal c-cmaes', but
-    it must be an orthonormal eigenbasis of the device's C, ascending, and the run must keep converging."""
+    """"device_eigen": this library's one-sided Jacobi eigendecomposition on the GPU (fp64).  The basis need not equal
+    c-cmaes' (signs, order, degenerate subspaces), but it must be an orthonormal eigenbasis of the device's C, its
+    eigenvalues must agree with an independent fp64 solver to 1e-10 relative, and the run must keep converging."""
     from ddrl_amd.cmaes import Cmaes
     N, lam = 40, 64
     es = Cmaes(np.linspace(0.5, 1.5, N), [0.3] * N, 5, lam)
@@ -205,12 +206,76 @@ def test_device_eigen_throughput_mode():
         X = es.sample()
         if g > 0 and int(es.get("eigen_uptodate")) == 1:
             B, D, Cm = es.vec("B"), es.vec("D"), C_prev
-            assert np.max(np.abs(B.T @ B - np.eye(N))) < 1e-5
-            assert np.all(np.diff(D) >= 0)
-            assert nerr(B @ np.diag(D * D) @ B.T, Cm) < 1e-5
+            assert np.max(np.abs(B.T @ B - np.eye(N))) < 1e-6          # B as the device holds it: fp32
+            assert nerr(B @ np.diag(D * D) @ B.T, Cm) < 1e-6
+            ev = np.linalg.eigvalsh(Cm)
+            assert np.max(np.abs(np.sort(D * D) - ev)) <= 1e-10 * ev.max()
+            assert 1 <= int(es.get("eigen_sweeps")) <= 20
         f = ((X - 0.2) ** 2).sum(1)
         f0 = f.min() if f0 is None else f0
         es.update(f)
         C_prev = es.vec("C")
     assert f.min() < 0.2 * f0
     es.close()
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 151])
+def test_device_eigen_against_the_host_routines(N):
+    """the same covariance through both eigensolvers: host Householder + QL (parity mode, c-cmaes' routines) and the device
+    Jacobi kernels -- eigenvalues to 1e-10 relative, and both bases diagonalise C; odd, even and trivial sizes"""
+    from ddrl_amd.cmaes import Cmaes
+    lam = max(8, 2 * N)
+    res = []
+    for dev in (0, 1):
+        es = Cmaes(np.linspace(-0.5, 0.5, N) if N > 1 else np.zeros(1), np.linspace(0.2, 0.6, N) if N > 1 else [0.3], 7, lam)
+        es.set_option("device_eigen", dev)
+        for g in range(3):                          # three updates from the c-cmaes stream: identical C in both runs
+            X = es.sample()
+            if g == 1:
+                res.append((es.vec("C"), es.vec("B"), es.vec("D")))
+            es.update(((X - 0.1) ** 2).sum(1) + np.arange(lam) * 1e-9)
+        es.close()
+    (C0, B0, D0), (C1, B1, D1) = res
+    assert np.array_equal(C0, C1)                   # generation 1 sampled from the initial (diagonal) C in both
+    ev0, ev1 = np.sort(D0 * D0), np.sort(D1 * D1)
+    assert np.max(np.abs(ev0 - ev1)) <= 1e-10 * ev0.max()
+    for B, D in ((B0, D0), (B1, D1)):
+        assert nerr(B @ np.diag(D * D) @ B.T, C0) < 1e-6               # B as the device holds it: fp32
+        assert np.max(np.abs(B.T @ B - np.eye(N))) < 1e-6
+
+
+def test_update_dev_equals_update_and_device_generation():
+    """ddrl_cmaes_update_dev on a device buffer (what the RCCL fitness all-gather produces, ddrl_amd/shard.py) == ddrl_cmaes_update
+    on the same values from the host, bit for bit; and ShardedCmaes.generation_dev (torch view of the library's X, fitness
+    computed on the device, gathered tensor's address into update_dev) == the host loop, world = 1."""
+    import torch
+    from ddrl_amd.cmaes import Cmaes
+    from ddrl_amd.shard import ShardedCmaes
+    N, lam = 24, 50
+    a, b, c = (Cmaes(np.linspace(-1, 1, N), [0.4] * N, 9, lam) for _ in range(3))
+    sh = ShardedCmaes(c, lam, 0, 1)
+    for g in range(4):
+        Xa, Xb = a.sample(), b.sample()
+        assert np.array_equal(Xa, Xb)
+        f = ((Xa - 0.3) ** 2).sum(1)
+        f[5] = f[17]                                                   # a tie: the later index ranks first
+        a.update(f)
+        d_f = torch.from_numpy(f).cuda()
+        torch.cuda.synchronize()
+        b.update_dev(d_f.data_ptr())
+        for key in ("xmean", "ps", "pc", "C"):
+            assert np.array_equal(a.vec(key), b.vec(key)), (g, key)
+        assert a.get("sigma") == b.get("sigma") and np.array_equal(a.index(), b.index())
+
+        def fit_dev(Xblk):
+            ft = ((Xblk.double() - 0.3) ** 2).sum(1)
+            ft[5] = ft[17]
+            return ft
+        fc = sh.generation_dev(fit_dev).cpu().numpy()
+        Xc = c.population()
+        assert np.array_equal(Xc, Xa)                                  # same seed, same stream
+        assert np.allclose(fc, f, rtol=1e-12)                          # (torch's and numpy's row sums may differ in the last bit)
+        assert np.array_equal(c.index(), a.index()) or not np.array_equal(fc, f)
+    for e in (a, b, c):
+        e.close()
+

@@ -61,7 +61,7 @@ def test_survey_known_answer(ora):
     assert c.vec("ps")[0] == 0.13722626374428595 and c.vec("pc")[0] == 0.13699777064836419
 
 
-@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big", "term_flat", "term_noeffect", "term_sphere"])
+@pytest.mark.parametrize("name", ["n5", "n12_ties", "n40", "n151", "n151_big", "n631_big", "term_flat", "term_noeffect", "term_sphere"])
 def test_golden_runs(ora, name):
     g = load(name)
     N, lam = g["N"], g["lambda"]

@@ -37,14 +37,16 @@ def test_all_gather_world1():
         all_gather_fitness(f, 6, 0, 1)
 
 
+@pytest.mark.parametrize("flavour", ["host", "dev"])
 @pytest.mark.parametrize("lam", [8, 9])          # even and uneven blocks
-def test_sharded_cmaes_gloo_world2(ora, tmp_path, lam):
+def test_sharded_cmaes_gloo_world2(ora, tmp_path, lam, flavour):
+    """flavour dev: ShardedCmaes.generation_dev -- tensors gathered in place, the gathered buffer's address into update_dev"""
     N, gens = 6, 5
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(29500 + lam),
-           os.path.join(ROOT, "tests", "shard_worker.py"), out, str(lam), str(N), str(gens)]
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + lam + (20 if flavour == "dev" else 0)),
+           os.path.join(ROOT, "tests", "shard_worker.py"), out, str(lam), str(N), str(gens), flavour]
     subprocess.run(cmd, check=True, env=env, timeout=240, cwd=ROOT)
     res = [json.load(open("%s.%d" % (out, r))) for r in range(2)]
     # single-process reference run
@@ -52,7 +54,12 @@ def test_sharded_cmaes_gloo_world2(ora, tmp_path, lam):
     fits = []
     for _ in range(gens):
         X = es.sample()
-        f = (X * X).sum(1)
+        if flavour == "dev":
+            import torch
+            t = torch.from_numpy(X)
+            f = (t * t).sum(1).numpy()
+        else:
+            f = (X * X).sum(1)
         fits.append(f.tolist())
         es.update(f)
     for r in res:
