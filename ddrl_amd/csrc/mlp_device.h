@@ -52,9 +52,27 @@ __device__ __forceinline__ void ddrl_sync() {
 __device__ __forceinline__ void ddrl_sync() { __syncthreads(); }
 #endif
 
+#ifndef DDRL_F64_DEBUG
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+#else
+// fp64 debug build: the same 16 x 16 x 4 product as an fma chain over k = 0..3 in the MFMA's order, operands fetched
+// from the lanes that hold them (lane (c, g): A[i = c][k = g], B[k = g][j = c]; result reg r: D[4g + r][c])
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float acc = c[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc = fma(__shfl(a, k * 16 + 4 * g + r), __shfl(b, k * 16 + col), acc);
+    c[r] = acc;
+  }
+  return c;
+}
+#endif
+// leaky-ReLU slope (Caffe ReLULayer negative_slope, MLP.hpp:888-897) in the arithmetic type
+constexpr float kLeaky = (float)0.01;
 __device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
 // Hides a (uniform) pointer's provenance from the optimiser: the same weights are walked by several
 // passes of one kernel, and without this the per-lane addresses of ALL passes are computed once,
@@ -92,7 +110,7 @@ __device__ __forceinline__ void l2_touch_block(const float *base, int floats, fl
 // Caffe ReLULayer (negative_slope 0.01 for hidden_layer_type 1, MLP.hpp:888-897), TanHLayer
 __device__ __forceinline__ float act_fwd(int t, float x) {
   switch (t) {
-    case 1: return x > 0.f ? x : 0.01f * x;
+    case 1: return x > 0.f ? x : kLeaky * x;
     case 2: return tanhf(x);
     case 3: return x > 0.f ? x : 0.f;
     default: return x;
@@ -101,7 +119,7 @@ __device__ __forceinline__ float act_fwd(int t, float x) {
 // in-place layers (top == bottom, MLP.hpp:799-803): the derivative is taken from the OUTPUT y
 __device__ __forceinline__ float act_bwd(int t, float y, float dy) {
   switch (t) {
-    case 1: return y > 0.f ? dy : 0.01f * dy;
+    case 1: return y > 0.f ? dy : kLeaky * dy;
     case 2: return dy * (1.f - y * y);
     case 3: return y > 0.f ? dy : 0.f;
     default: return dy;
@@ -305,7 +323,11 @@ struct OptCtx {
 // IEEE expansions of sqrtf and '/': v >= 0 and the divisor is >= eps = 1e-8, well inside the normal
 // range, and a denormal v (where v_sqrt_f32 is inexact) is below eps^2 and changes nothing.
 __device__ __forceinline__ float adam_rdenom(float v, float eps) {
+#ifdef DDRL_F64_DEBUG
+  return 1.0 / (sqrt(v) + eps);
+#else
   return __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
+#endif
 }
 
 // NT: optimiser state other than the weights is touched once per update and is streamed past the
@@ -330,7 +352,11 @@ template <bool NT> __device__ __forceinline__ void stream_st(float *p, f32x4 x) 
 // (`buffer_wbl2`) at its release -- only every storing wave's vmcnt(0), the barrier and the flag.  16-byte
 // sc1 stores run at the plain rate; the 4-byte ones (biases, counters) are few.
 __device__ __forceinline__ void store_sc1(float *p, f32x4 x) {
+#ifdef DDRL_F64_DEBUG
+  *(f32x4 *)p = x;     // (the debug build runs one update per launch: nothing is handed to another workgroup)
+#else
   asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+#endif
 }
 __device__ __forceinline__ void store_sc1(float *p, float x) {
   __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -43,7 +43,11 @@ hipError_t ewc_cost_launch(const float *w, const float *wstar, const float *fhat
 }
 
 // ---------------------------------------------------------------------------------------------
-extern "C" const char *ddrl_version(void) { return "ddrl_amd 0.1 (gfx950)"; }
+#ifdef DDRL_F64_DEBUG
+extern "C" const char *ddrl_version(void) { return "ddrl_amd 0.2 (gfx950) +f64 debug build: the one-tile DDPG path in fp64, float arguments of the ABI are double"; }
+#else
+extern "C" const char *ddrl_version(void) { return "ddrl_amd 0.2 (gfx950)"; }
+#endif
 
 extern "C" int ddrl_ddpg_config_default(ddrl_ddpg_config *c) {
   if (!c) return ddrl_fail(DDRL_EINVAL, "cfg is NULL");
@@ -275,7 +279,7 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
                            case 2: b1 = 0.; b2 = 0.; break; default: b1 = 0.9; b2 = 0.; }
   h->beta1 = b1; h->beta2 = b2;
   P.beta1 = (float)b1; P.beta2 = (float)b2; P.omb1 = (float)(1. - b1); P.omb2 = (float)(1. - b2);
-  P.eps = 1e-8f;   // caffe SolverParameter.delta default
+  P.eps = (float)1e-8;   // caffe SolverParameter.delta default
   P.fisher_beta = (float)cfg->ewc_fisher_beta;
   P.rep = h->d_rep; P.rep_len = h->d_len; P.rep_head = h->d_head; P.idx = h->d_idx;
   P.tau = h->d_tau; P.omtau = h->d_omtau; P.gamma = h->d_gamma;
@@ -490,10 +494,10 @@ extern "C" int ddrl_pop_replay_append(ddrl_pop_t *h, const float *s, const float
   const int G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
   const uint8_t *dmask;
   if ((rc = upload_mask(h, mask, &dmask))) return rc;
-  HIPCHK(hipMemcpyAsync(h->d_s, s, (size_t)G * S * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_a, a, (size_t)G * A * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_r, r, (size_t)G * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_s2, s2, (size_t)G * S * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_s, s, (size_t)G * S * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_a, a, (size_t)G * A * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_r, r, (size_t)G * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_s2, s2, (size_t)G * S * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_goal, goal, (size_t)G, hipMemcpyHostToDevice, h->stream));
   HIPCHK(replay_append_launch(h->d_rep, h->d_len, h->d_head, G, h->cfg.replay_memory, h->rowlen, S, A,
                               h->d_s, h->d_a, h->d_r, h->d_s2, h->d_goal, dmask, h->stream));
@@ -563,9 +567,9 @@ extern "C" int ddrl_pop_infer(ddrl_pop_t *h, const float *states, float *actions
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
-  HIPCHK(hipMemcpyAsync(h->d_s, states, (size_t)G * S * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_s, states, (size_t)G * S * sizeof(float), hipMemcpyHostToDevice, h->stream));
   if ((rc = ddrl_pop_infer_dev(h, h->d_s, h->d_act))) return rc;
-  HIPCHK(hipMemcpyAsync(actions, h->d_act, (size_t)G * A * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(actions, h->d_act, (size_t)G * A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   DDRL_WAIT(h);
   return DDRL_OK;
 }
@@ -776,8 +780,8 @@ extern "C" int ddrl_pop_td3_last(ddrl_pop_t *h, float *loss2, float *noise) {
   int rc = set_device(h);
   if (rc) return rc;
   const size_t G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;
-  if (loss2) HIPCHK(hipMemcpyAsync(loss2, h->d_loss2, G * 4, hipMemcpyDeviceToHost, h->stream));
-  if (noise) HIPCHK(hipMemcpyAsync(noise, h->d_noise, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));
+  if (loss2) HIPCHK(hipMemcpyAsync(loss2, h->d_loss2, G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (noise) HIPCHK(hipMemcpyAsync(noise, h->d_noise, G * B * A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   DDRL_WAIT(h);
   return DDRL_OK;
 }
@@ -799,9 +803,9 @@ extern "C" int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, floa
     const size_t nu = h->P.nupd > 0 ? h->P.nupd : 1;
     HIPCHK(hipMemcpy2DAsync(idx, B * 4, h->d_idx + (nu - 1) * B, nu * B * 4, B * 4, G, hipMemcpyDeviceToHost, h->stream));
   }
-  if (loss) HIPCHK(hipMemcpyAsync(loss, h->d_loss, G * 4, hipMemcpyDeviceToHost, h->stream));
-  if (qt) HIPCHK(hipMemcpyAsync(qt, h->d_qt, G * B * 4, hipMemcpyDeviceToHost, h->stream));
-  if (dact) HIPCHK(hipMemcpyAsync(dact, h->d_dact, G * B * A * 4, hipMemcpyDeviceToHost, h->stream));
+  if (loss) HIPCHK(hipMemcpyAsync(loss, h->d_loss, G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (qt) HIPCHK(hipMemcpyAsync(qt, h->d_qt, G * B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (dact) HIPCHK(hipMemcpyAsync(dact, h->d_dact, G * B * A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   DDRL_WAIT(h);
   return DDRL_OK;
 }
@@ -836,8 +840,8 @@ extern "C" int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *act
   const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
   std::vector<float> sg(G * S, 1.f), ag(G * A, 1.f);
   if (h->gates_on) {
-    HIPCHK(hipMemcpyAsync(sg.data(), h->d_sgate, sg.size() * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(ag.data(), h->d_agate, ag.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(sg.data(), h->d_sgate, sg.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ag.data(), h->d_agate, ag.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     DDRL_WAIT(h);
   }
   if (state_gate) for (size_t i = 0; i < G * S; ++i) state_gate[i] = sg[i];
@@ -943,7 +947,7 @@ extern "C" int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost) {
   if (!t.ewc.enabled) return DDRL_OK;
   HIPCHK(ewc_cost_launch(t.st.w, t.st.wstar, t.st.fhat, t.nd.stride(), h->d_cost, h->G, h->stream));
   std::vector<float> c(h->G);
-  HIPCHK(hipMemcpyAsync(c.data(), h->d_cost, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(c.data(), h->d_cost, h->G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   DDRL_WAIT(h);
   for (int g = 0; g < h->G; ++g) {
     if (!t.ewc.live[g]) continue;
@@ -965,7 +969,7 @@ extern "C" int ddrl_pop_get_ewc(ddrl_pop_t *h, int net, double *fisher, double *
   if (wstar && (rc = download_flat(h, t.nd, t.st.wstar, wstar))) return rc;
   if (fisher_nbr) {
     std::vector<float> f(h->G);
-    HIPCHK(hipMemcpyAsync(f.data(), t.st.fisher_nbr, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(f.data(), t.st.fisher_nbr, h->G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     DDRL_WAIT(h);
     for (int g = 0; g < h->G; ++g) fisher_nbr[g] = f[g];
   }
@@ -1064,7 +1068,7 @@ extern "C" int ddrl_pop_profile_read(ddrl_pop_t *h, double *kernel_ms, int *laun
   DDRL_WAIT(h);
   double tot = 0.;
   for (size_t i = 0; i < h->ev_used; ++i) {
-    float ms = 0.f;
+    ddrl_f32 ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
     tot += ms;
   }

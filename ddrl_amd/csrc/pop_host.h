@@ -1,8 +1,8 @@
 // pop_host.h -- host-side handle of libddrl_pop.so and the helpers shared by pop.hip (DDPG) and
 // nfac.hip (NFAC(lambda)-V).  Not part of the C ABI.
 #pragma once
+#include "pop_internal.h"            // first: the fp64 debug build retypes `float` for everything after it
 #include "../../include/ddrl_pop.h"
-#include "pop_internal.h"
 #include "host_util.h"
 #include "ckpt.h"
 

@@ -3,6 +3,43 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- DDRL_F64_DEBUG: the fp64 debug instantiation of the fused DDPG update (`make f64`) ----
+// The SAME sources with every `float` of the device state, the LDS tiles and the arithmetic turned into `double`
+// (the matrix products run as fp64 fma chains in the MFMA's own order, mlp_device.h).  It exists to separate
+// rounding from algorithm: device-fp64 against the fp64 oracle agrees to ~1e-12 over 100 free-running updates
+// (tests/test_f64_debug_gpu.py), so what the fp32 product differs by is rounding.  Speed is irrelevant; only the
+// one-tile DDPG path is built (libddrl_pop_f64.so: pop.hip, kernels_ddpg.hip, kernels_misc.hip).  In this build the
+// C ABI's `float` arrays are `double` arrays too (ddrl_version() says "+f64"; ddrl_amd/lib.py follows).
+// Every system header goes in BEFORE the macro: the standard library specialises on both types.
+typedef float ddrl_f32;        // a real fp32 where an outside API wants one (hipEventElapsedTime)
+#ifdef DDRL_F64_DEBUG
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+#define float double
+#define tanhf tanh
+#define fmaxf fmax
+#endif
+
 #define DDRL_MAXL 4          // InnerProduct layers per net = hidden (<=3) + output
 #define DDRL_MB 64           // rows per workgroup batch tile (4 MFMA m-tiles of 16)
 #ifndef DDRL_NWAVES

@@ -1,11 +1,14 @@
 """ctypes loader of libddrl_pop.so.  Fails loudly: there is no fallback."""
 import ctypes as C
 import os
+
+import numpy as np
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.environ.get("DDRL_POP_SO") or os.path.join(HERE, "libddrl_pop.so")   # DDRL_POP_SO: dev experiments only
 DDRL_MAX_HIDDEN = 3
+REAL = np.float32            # what a `float` of the C ABI is in the loaded library (float64 in the fp64 debug build)
 
 
 class LibraryMissing(RuntimeError):
@@ -212,7 +215,13 @@ def load():
             "%s not found: build it with `make -C ddrl_amd/csrc` (or __graft_entry__.build()). "
             "ddrl_amd has no CPU path." % SO)
     L = C.CDLL(SO)
+    L.ddrl_version.restype = _cp
+    global REAL
+    partial = b"+f64" in L.ddrl_version()    # the fp64 debug build (csrc/pop_internal.h): the one-tile DDPG path only,
+    REAL = np.float64 if partial else np.float32   # and the ABI's float arrays are double arrays
     for name, res, args in SYMBOLS:
+        if partial and not hasattr(L, name):
+            continue
         fn = getattr(L, name)     # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

@@ -102,18 +102,18 @@ class Population:
 
     # ann_testing->computeOut(sensors) for every agent
     def infer(self, states):
-        s = np.ascontiguousarray(states, np.float32).reshape(self.G, self.S)
-        out = np.empty((self.G, self.A), np.float32)
+        s = np.ascontiguousarray(states, _l.REAL).reshape(self.G, self.S)
+        out = np.empty((self.G, self.A), _l.REAL)
         _l.check(self.L.ddrl_pop_infer(self.h, _p(s), _p(out)))
         return out
 
     # MLP::computeOutBatch / computeOutVFBatch: x [G x n x in_dim] -> [G x n x out_dim]
     def forward_batch(self, net, x):
-        x = np.ascontiguousarray(x, np.float32)
+        x = np.ascontiguousarray(x, _l.REAL)
         x = x.reshape(self.G, -1, x.shape[-1])
         n = x.shape[1]
         dl = {0: self.A, 2: self.A}.get(net, 1)
-        out = np.empty((self.G, n, dl), np.float32)
+        out = np.empty((self.G, n, dl), _l.REAL)
         _l.check(self.L.ddrl_pop_forward_batch(self.h, net, n, _p(x), _p(out)))
         return out
 
@@ -194,15 +194,15 @@ class DdpgPopulation(Population):
         _l.check(self.L.ddrl_pop_seed_replay(self.h, _p(s)))
 
     def replay_append(self, s, a, r, s2, goal, mask=None):
-        f = lambda x, n: np.ascontiguousarray(x, np.float32).reshape(self.G, n)
+        f = lambda x, n: np.ascontiguousarray(x, _l.REAL).reshape(self.G, n)
         s, a, s2 = f(s, self.S), f(a, self.A), f(s2, self.S)
-        r = np.ascontiguousarray(r, np.float32).reshape(self.G)
+        r = np.ascontiguousarray(r, _l.REAL).reshape(self.G)
         goal = np.ascontiguousarray(goal, np.uint8).reshape(self.G)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
         _l.check(self.L.ddrl_pop_replay_append(self.h, _p(s), _p(a), _p(r), _p(s2), _p(goal), _p(m)))
 
     def replay_load(self, agent, rows):
-        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 2 * self.S + self.A + 2)
+        rows = np.ascontiguousarray(rows, _l.REAL).reshape(-1, 2 * self.S + self.A + 2)
         _l.check(self.L.ddrl_pop_replay_load(self.h, agent, rows.shape[0], _p(rows)))
 
     def replay_len(self):
@@ -224,9 +224,9 @@ class DdpgPopulation(Population):
 
     def last(self):
         idx = np.empty((self.G, self.B), np.int32)
-        loss = np.empty(self.G, np.float32)
-        qt = np.empty((self.G, self.B), np.float32)
-        da = np.empty((self.G, self.B, self.A), np.float32)
+        loss = np.empty(self.G, _l.REAL)
+        qt = np.empty((self.G, self.B), _l.REAL)
+        da = np.empty((self.G, self.B, self.A), _l.REAL)
         _l.check(self.L.ddrl_pop_ddpg_last(self.h, _p(idx), _p(loss), _p(qt), _p(da)))
         return dict(idx=idx, loss=loss, q_targets=qt, dact=da)
 
