@@ -6,7 +6,7 @@
 // ---- DDRL_F64_DEBUG: the fp64 debug instantiation of the fused DDPG update (`make f64`) ----
 // The SAME sources with every `float` of the device state, the LDS tiles and the arithmetic turned into `double`
 // (the matrix products run as fp64 fma chains in the MFMA's own order, mlp_device.h).  It exists to separate
-// rounding from algorithm: device-fp64 against the fp64 oracle agrees to ~1e-12 over 100 free-running updates
+// rounding from algorithm: device-fp64 against the fp64 CPU restatement agrees to ~1e-14 over 100 free-running updates
 // (tests/test_f64_debug_gpu.py), so what the fp32 product differs by is rounding.  Speed is irrelevant; only the
 // one-tile DDPG path is built (libddrl_pop_f64.so: pop.hip, kernels_ddpg.hip, kernels_misc.hip).  In this build the
 // C ABI's `float` arrays are `double` arrays too (ddrl_version() says "+f64"; ddrl_amd/lib.py follows).
