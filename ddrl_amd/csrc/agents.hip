@@ -32,6 +32,9 @@ struct DevCfg {
   bool on = false, disable_st = false;
   std::vector<long> st_control, ac_control, devpoints;
   bool im = false, reset_learning_algo = false, informed = false;
+  int heuristic = 1;                         // 1: switches at heuristic_devpoints, 2: linear ramps of Bernoulli gates
+  bool st_scale = false, ac_scale = false;
+  std::vector<double> linearcoef;            // heuristic 2 (DODevMLP.hpp:123-130, 444-467)
   int im_smooth = 0, im_window = 0;
   std::vector<double> pd;                    // pd_controller_factor [nb_motors]
 };
@@ -140,9 +143,21 @@ extern "C" int ddrl_agents_destroy(ddrl_agents_t *h) {
   return DDRL_OK;
 }
 
+// bib::to_array<double>: ':' separated
+static std::vector<double> colon_doubles(const std::string &raw) {
+  std::vector<double> out;
+  for (size_t pos = 0; pos <= raw.size();) {
+    size_t e = raw.find(':', pos);
+    if (e == std::string::npos) e = raw.size();
+    if (e > pos) out.push_back(std::stod(raw.substr(pos, e - pos)));
+    pos = e + 1;
+  }
+  return out;
+}
+
 // DODevMLP::exploit (DODevMLP.hpp:76-214): the [devnn] keys, with the reference's consistency checks
 // as errors instead of exit(1).  Active when the ini has devnn.st_control.
-static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path) {
+static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path, uint64_t seed) {
   DevCfg &d = h->dev;
   if (!ini.has("devnn.st_control")) return DDRL_OK;
   try {
@@ -153,28 +168,33 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path) {
     d.ac_control = ini.get_list("devnn.ac_control");
     const long heuristic = ini.has("devnn.heuristic") ? ini.get_long("devnn.heuristic") : 0;
     if (heuristic == 0) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = 0 (gate weights learned by backpropagation) is not supported");
-    if (heuristic == 2) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = 2 needs probabilistic gates (st/ac_probabilistic = 0), which are not supported");
-    if (heuristic != 1) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = %ld unknown", heuristic);
-    if (st_prob != 1 || ac_prob != 1) return ddrl_fail(DDRL_EINVAL, "heuristic is 1 so probabilistic should be 1");     // :90-93
-    if (st_scale || ac_scale) return ddrl_fail(DDRL_EINVAL, "if not probabilistic then why scaling? of how much?");     // :192-195
+    if (heuristic != 1 && heuristic != 2) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = %ld unknown", heuristic);
+    if (heuristic == 1 && (st_prob != 1 || ac_prob != 1)) return ddrl_fail(DDRL_EINVAL, "heuristic is 1 so probabilistic should be 1");   // :90-93
+    if (heuristic == 2 && (st_prob != 0 || ac_prob != 0)) return ddrl_fail(DDRL_EINVAL, "heuristic is 2 so probabilistic should be 0");   // :94-97
+    if ((ac_scale && ac_prob != 0) || (st_scale && st_prob != 0))
+      return ddrl_fail(DDRL_EINVAL, "if not probabilistic then why scaling? of how much?");                              // :192-195
+    d.heuristic = (int)heuristic; d.st_scale = st_scale; d.ac_scale = ac_scale;
     if (ini.has("devnn.intrasec_motivation")) d.im = ini.get_bool("devnn.intrasec_motivation");
+    if (d.im && heuristic != 1)
+      return ddrl_fail(DDRL_EINVAL, "intrasec motiv works only with determinist activation and heuristic = 1");          // :104-107
     if (d.im) { d.im_smooth = (int)ini.get_long("devnn.im_smooth"); d.im_window = (int)ini.get_long("devnn.im_window"); }
-    d.devpoints = ini.get_list("devnn.heuristic_devpoints");
-    if (d.devpoints.size() != d.st_control.size() + d.ac_control.size())                 // :119-120
-      return ddrl_fail(DDRL_EINVAL, "heuristic_devpoints has %zu entries for %zu + %zu controlled dimensions", d.devpoints.size(),
-                       d.st_control.size(), d.ac_control.size());
+    if (heuristic == 1) {
+      d.devpoints = ini.get_list("devnn.heuristic_devpoints");
+      if (d.devpoints.size() != d.st_control.size() + d.ac_control.size())                 // :119-120
+        return ddrl_fail(DDRL_EINVAL, "heuristic_devpoints has %zu entries for %zu + %zu controlled dimensions", d.devpoints.size(),
+                         d.st_control.size(), d.ac_control.size());
+    } else {
+      d.linearcoef = colon_doubles(ini.get("devnn.heuristic_linearcoef"));
+      if (d.linearcoef.size() < d.st_control.size() + d.ac_control.size())                 // :126-127
+        return ddrl_fail(DDRL_EINVAL, "heuristic_linearcoef has %zu entries for %zu + %zu controlled dimensions", d.linearcoef.size(),
+                         d.st_control.size(), d.ac_control.size());
+    }
     if (ini.has("devnn.compute_diff_backward") && ini.get_bool("devnn.compute_diff_backward"))
       return ddrl_fail(DDRL_EINVAL, "why do you compute diff if you don't use local solver?");                         // :207-210
     if (ini.has("devnn.reset_learning_algo")) d.reset_learning_algo = ini.get_bool("devnn.reset_learning_algo");
     if (ini.has("devnn.informed_sensorimotor_space")) d.informed = ini.get_bool("devnn.informed_sensorimotor_space");
     if (d.informed) {
-      const std::string raw = ini.get("devnn.pd_controller_factor");
-      for (size_t pos = 0; pos <= raw.size();) {                                         // bib::to_array<double>: ':' separated
-        size_t e = raw.find(':', pos);
-        if (e == std::string::npos) e = raw.size();
-        if (e > pos) d.pd.push_back(std::stod(raw.substr(pos, e - pos)));
-        pos = e + 1;
-      }
+      d.pd = colon_doubles(ini.get("devnn.pd_controller_factor"));
       if ((int)d.pd.size() != h->A) return ddrl_fail(DDRL_EINVAL, "wrong pd_controller_factor %zu", d.pd.size());       // :155-158
     }
   } catch (const std::exception &e) {
@@ -184,22 +204,33 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path) {
   if (d.st_control.empty() && !d.disable_st) return ddrl_fail(DDRL_EINVAL, "devnn.st_control: list the gated dimensions or None");
   for (long c : d.st_control) if (c < 0 || c >= h->S) return ddrl_fail(DDRL_EINVAL, "devnn.st_control %ld outside 0..%d", c, h->S - 1);
   for (long c : d.ac_control) if (c < 0 || c >= h->A) return ddrl_fail(DDRL_EINVAL, "devnn.ac_control %ld outside 0..%d", c, h->A - 1);
+  if (d.heuristic == 2 && d.informed) return ddrl_fail(DDRL_EINVAL, "informed_sensorimotor_space is not implemented with proba action");   // :161-169
+  if (d.heuristic == 2 && d.reset_learning_algo) return ddrl_fail(DDRL_EINVAL, "when sould I reset ? I'm progressive");                    // :197-200
+  if (d.heuristic == 2 && h->algo == 3) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the TD3 update");
   if (h->algo == 1 && d.reset_learning_algo) return ddrl_fail(DDRL_EINVAL, "NFAC cannot reset anything with DODevMLP");   // OfflineCaclaAg.hpp:199-203
   if (h->algo == 2) return ddrl_fail(DDRL_EINVAL, "the developmental schedule is not supported for CMA-ES agents");
+  if (d.heuristic == 2) {
+    int rc = ddrl_pop_set_gate_mode(h->pop, 1, d.st_scale ? 1 : 0, 1, d.ac_scale ? 1 : 0, (uint32_t)(seed * 2246822519ull + 374761393u));
+    if (rc) return rc;
+  }
   d.on = true;
   h->devst.resize(h->G);
   for (auto &st : h->devst) { st.st_w.assign(d.st_control.size(), 0.); st.ac_w.assign(d.ac_control.size(), 0.); }
   return DDRL_OK;
 }
 
-// the deterministic Developmental layer (probabilist = 1): a controlled dimension whose weight is
-// below 0.5 is forced to 0, every other one passes
+// the gate weights into the population.  Deterministic Developmental layer (probabilist = 1, heuristic 1): a controlled
+// dimension whose weight is below 0.5 is forced to 0, every other one passes.  Probabilistic layer
+// (heuristic 2): the weight itself is the pass probability (capped at 1: episode x coefficient grows without bound in
+// the reference, DODevMLP.hpp:453, and what its layer does with w > 1 is not pinned by any test in the tree).
 static int push_gates(ddrl_agents *h) {
   const DevCfg &d = h->dev;
   std::vector<double> sg((size_t)h->G * h->S, 1.), ag((size_t)h->G * h->A, 1.);
+  const bool prob = d.heuristic == 2;
+  auto gate = [prob](double w) { return prob ? std::min(1., std::max(0., w)) : (w < 0.5 ? 0. : 1.); };
   for (int g = 0; g < h->G; ++g) {
-    for (size_t i = 0; i < d.st_control.size(); ++i) sg[(size_t)g * h->S + d.st_control[i]] = h->devst[g].st_w[i] < 0.5 ? 0. : 1.;
-    for (size_t i = 0; i < d.ac_control.size(); ++i) ag[(size_t)g * h->A + d.ac_control[i]] = h->devst[g].ac_w[i] < 0.5 ? 0. : 1.;
+    for (size_t i = 0; i < d.st_control.size(); ++i) sg[(size_t)g * h->S + d.st_control[i]] = gate(h->devst[g].st_w[i]);
+    for (size_t i = 0; i < d.ac_control.size(); ++i) ag[(size_t)g * h->A + d.ac_control[i]] = gate(h->devst[g].ac_w[i]);
   }
   return ddrl_pop_set_gates(h->pop, sg.data(), ag.data());
 }
@@ -225,6 +256,15 @@ static bool still_something(const DevCfg &d, const DevState &st) {
 // DODevMLP::inform (:566-574) for one agent: returns changed; *setup = ewc_setup() was called
 static bool dev_inform(const DevCfg &d, DevState &st, int episode, double score, bool *setup) {
   *setup = false;
+  if (d.heuristic == 2) {                                              // develop (:444-467): every episode, ewc_setup() first
+    for (size_t i = 0; i < d.st_control.size(); ++i) st.st_w[i] = d.linearcoef[i] >= 1. ? 1. : (double)episode * d.linearcoef[i];
+    for (size_t i = 0; i < d.ac_control.size(); ++i) {
+      const double c = d.linearcoef[i + d.st_control.size()];
+      st.ac_w[i] = c >= 1. ? 1. : (double)episode * c;
+    }
+    *setup = true;
+    return true;
+  }
   if (!d.im) {                                                         // develop (:420-470), heuristic 1
     bool changed = false;
     for (size_t i = 0; i < d.devpoints.size(); ++i)
@@ -338,7 +378,7 @@ extern "C" int ddrl_agents_create_ddpg(const char *ini_path, int n_agents, int n
   if ((rc = ddrl_ddpg_create(&cfg, seed, &h->pop))) return rc;
   h->force_more_update = cfg.force_more_update;
   init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
-  if ((rc = read_devnn(h.get(), ini, ini_path)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
+  if ((rc = read_devnn(h.get(), ini, ini_path, seed)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
   std::vector<uint32_t> rs(cfg.n_agents);
   for (int g = 0; g < cfg.n_agents; ++g) rs[g] = (uint32_t)(seed * 40503ull + 7919u * g + 17u);
   if ((rc = ddrl_pop_seed_replay(h->pop, rs.data()))) { ddrl_agents_destroy(h.release()); return rc; }
@@ -365,7 +405,7 @@ extern "C" int ddrl_agents_create_td3(const char *ini_path, int n_agents, int nb
   h->policy_freq = cfg.policy_freq;
   if ((rc = ddrl_td3_create(&cfg, seed, &h->pop))) return rc;
   init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
-  if ((rc = read_devnn(h.get(), ini, ini_path)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
+  if ((rc = read_devnn(h.get(), ini, ini_path, seed)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
   std::vector<uint32_t> rs(cfg.n_agents);
   for (int g = 0; g < cfg.n_agents; ++g) rs[g] = (uint32_t)(seed * 40503ull + 7919u * g + 17u);
   if ((rc = ddrl_pop_seed_replay(h->pop, rs.data()))) { ddrl_agents_destroy(h.release()); return rc; }
@@ -400,7 +440,7 @@ extern "C" int ddrl_agents_create_nfac(const char *ini_path, int n_agents, int n
   h->gamma = cfg.gamma;
   if ((rc = ddrl_nfac_create(&cfg, seed, &h->pop))) return rc;
   init_state(h.get(), cfg.n_agents, cfg.nb_sensors, cfg.nb_motors, seed);
-  if ((rc = read_devnn(h.get(), ini, ini_path)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
+  if ((rc = read_devnn(h.get(), ini, ini_path, seed)) || (h->dev.on && (rc = push_gates(h.get())))) { ddrl_agents_destroy(h.release()); return rc; }
   *out = h.release();
   return DDRL_OK;
 }

@@ -35,7 +35,7 @@ struct LdsMap {
 // reward / goal into rv / dn.
 __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, int ldxc, int ldxa, int agent,
                                             const int *__restrict__ idx, int B, int head, bool next,
-                                            const LdsMap &M, int tid) {
+                                            const LdsMap &M, int tid, unsigned draw = 0) {
   // DDRL_NTHREADS / 64 threads per row, each with its own column residue: a thread reads idx[row] once
   // and its row loads are independent of each other, so the whole gather costs two memory round trips
   // (index, then row) instead of two per element
@@ -56,12 +56,21 @@ __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, i
     if (live) {
       if (next) { if (col < S) v = rr[S + A + col]; }
       else if (col < S + A) v = rr[col];
-      // developmental gates on the state inputs of both nets and on the critic's action input
-      if (sg && col < S) v *= sg[col];
-      if (ag && col >= S && col < S + A) v *= ag[col - S];
     }
-    M.xc[row * ldxc + col] = v;
-    if (col < ldxa) M.xa[row * ldxa + col] = col < S ? v : 0.f;
+    // developmental gates on the state inputs of both nets (each net's own layer instance: its own Bernoulli draw) and on
+    // the critic's action input
+    float vc = v, va = v;
+    if (live) {
+      const GateMode &gm = P.gm;
+      if (sg && col < S) {
+        vc *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_CRITIC_T_S : GS_CRITIC_S, row, col);
+        va *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_ACTOR_T_S : GS_ACTOR_S, row, col);
+      }
+      if (ag && col >= S && col < S + A)
+        vc *= ddrl_gate_factor(ag[col - S], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_CRITIC_A_REPLAY, row, col - S);
+    }
+    M.xc[row * ldxc + col] = vc;
+    if (col < ldxa) M.xa[row * ldxa + col] = col < S ? va : 0.f;
   }
   if (!next && q == 0) {
     M.rv[row] = live ? rr[2 * S + A] : 0.f;

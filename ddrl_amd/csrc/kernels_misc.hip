@@ -136,14 +136,16 @@ extern "C" __global__ void replay_append_kernel(float *__restrict__ rep, int *__
 // ------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(64)
 infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ states,
-             float *__restrict__ actions, const float *__restrict__ in_gate, const float *__restrict__ out_gate) {
+             float *__restrict__ actions, const float *__restrict__ in_gate, const float *__restrict__ out_gate,
+             const GateMode gm) {
   __shared__ __align__(16) float buf[2][DDRL_WIDE_MAXW + 8];
   const int agent = blockIdx.x, lane = threadIdx.x;
   const float *wa = w + (size_t)agent * nd.stride();
   const int d0 = nd.d(0);
   for (int k = lane; k < nd.kp(0); k += 64) {
     float x = k < d0 ? states[(size_t)agent * d0 + k] : 0.f;
-    if (in_gate && k < d0) x *= in_gate[(size_t)agent * d0 + k];
+    if (in_gate && k < d0)
+      x *= ddrl_gate_factor(in_gate[(size_t)agent * d0 + k], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, GS_INFER_S, 0, k);
     buf[0][k] = x;
   }
   __syncthreads();
@@ -167,7 +169,8 @@ infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restr
       }
       if (last) {
         if (n < N) {
-          if (out_gate) y *= out_gate[(size_t)agent * N + n];
+          if (out_gate)
+            y *= ddrl_gate_factor(out_gate[(size_t)agent * N + n], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_INFER_OUT, 0, n);
           actions[(size_t)agent * N + n] = y;
         }
       } else buf[cur ^ 1][n] = y;
@@ -281,8 +284,8 @@ extern "C" hipError_t replay_append_launch(float *rep, int *len, int *head, int 
   return hipGetLastError();
 }
 extern "C" hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, float *actions,
-                                   const float *in_gate, const float *out_gate, int G, hipStream_t st) {
-  hipLaunchKernelGGL(infer_kernel, dim3(G), dim3(64), 0, st, *nd, w, states, actions, in_gate, out_gate);
+                                   const float *in_gate, const float *out_gate, const GateMode *gm, int G, hipStream_t st) {
+  hipLaunchKernelGGL(infer_kernel, dim3(G), dim3(64), 0, st, *nd, w, states, actions, in_gate, out_gate, *gm);
   return hipGetLastError();
 }
 extern "C" hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st) {

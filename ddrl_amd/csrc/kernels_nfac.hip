@@ -30,11 +30,13 @@ static size_t nfac_lds_bytes(const NetDesc &nd, int ldh) {
 
 // 64 rows [row0, row0 + 64) of the state columns starting at `col0` of the trajectory into Xs
 __device__ __forceinline__ void load_states(const float *__restrict__ traj, int rowlen, int T, int row0, int col0,
-                                            int S, int ldx, const float *__restrict__ sgate, float *Xs, int tid) {
+                                            int S, int ldx, const float *__restrict__ sgate, float *Xs, int tid,
+                                            const GateMode &gm, int agent, int site) {
   for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
     const int row = e / ldx, col = e - row * ldx;
     float v = (row0 + row < T && col < S) ? traj[(size_t)(row0 + row) * rowlen + col0 + col] : 0.f;
-    if (sgate && col < S) v *= sgate[col];           // developmental state gate (shared by actor and critic)
+    // developmental state gate (weights shared by actor and critic; a Bernoulli draw per layer instance, pass and row)
+    if (sgate && col < S) v *= ddrl_gate_factor(sgate[col], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, site, row0 + row, col);
     Xs[e] = v;
   }
 }
@@ -58,7 +60,7 @@ nfac_values_kernel(const NfacParams P) {
   for (int pass = 0; pass < 2; ++pass) {
     if (!((P.value_passes >> pass) & 1)) continue;     // uniform
     load_states(traj, P.rowlen, T, row0, pass == 0 ? 0 : P.S + 2 * P.A, P.S, ldx,
-                P.sgate ? P.sgate + (size_t)agent * P.S : nullptr, M.x, tid);
+                P.sgate ? P.sgate + (size_t)agent * P.S : nullptr, M.x, tid, P.gm, agent, pass == 0 ? GS_NFAC_V_S : GS_NFAC_V_S2);
     __syncthreads();
     fwd_net(nv, nv.L(), w, M.x, ldx, M.hbase, M.hstride, M.top, ldt, wave, lane);
     float *out = (pass == 0 ? P.V : P.nextV) + (size_t)agent * P.maxT;
@@ -148,7 +150,8 @@ nfac_grad_kernel(const NfacParams P) {
   const size_t ro = (size_t)agent * P.maxT;
   const float *traj = P.traj + ro * P.rowlen;
   const float *w = st.w + (size_t)agent * nd.stride();
-  load_states(traj, P.rowlen, T, row0, 0, P.S, ldx, P.sgate ? P.sgate + (size_t)agent * P.S : nullptr, M.x, tid);
+  load_states(traj, P.rowlen, T, row0, 0, P.S, ldx, P.sgate ? P.sgate + (size_t)agent * P.S : nullptr, M.x, tid, P.gm, agent,
+              MODE == 0 ? GS_NFAC_V_S : GS_NFAC_A_S);
   __syncthreads();
   fwd_net(nd, nd.L(), w, M.x, ldx, M.hbase, M.hstride, M.top, ldt, wave, lane);
   if (MODE == 0) {
@@ -164,7 +167,8 @@ nfac_grad_kernel(const NfacParams P) {
     const int A = P.A;
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, h = e - row * A, li = row0 + row;
-      const float gt = P.agate ? P.agate[(size_t)agent * A + h] : 1.f;
+      const float gt = P.agate ? ddrl_gate_factor(P.agate[(size_t)agent * A + h], P.gm.ac_bern, P.gm.ac_scale, P.gm.seed, P.gm.draw, agent,
+                                                  GS_NFAC_A_OUT, li, h) : 1.f;
       const float raw = M.top[row * ldt + h];
       const float out = raw * gt;                                      // the actor's output gate
       float diff = 0.f;
@@ -338,7 +342,7 @@ extern "C" hipError_t nfac_finish_launch(const NfacParams *P, int critic_steps, 
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out,
                    int n, int ldh, const float *__restrict__ sgate, int S, const float *__restrict__ agate, int A,
-                   int gate_out) {
+                   int gate_out, const GateMode gm) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -350,8 +354,10 @@ net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *_
   for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
     const int row = e / ldx, col = e - row * ldx;
     float v = (row0 + row < n && col < d0) ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
-    if (sgate && col < S) v *= sgate[(size_t)agent * S + col];
-    if (agate && !gate_out && col >= S && col < S + A) v *= agate[(size_t)agent * A + col - S];   // critic's action input
+    if (sgate && col < S)
+      v *= ddrl_gate_factor(sgate[(size_t)agent * S + col], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, GS_BATCH_S, row0 + row, col);
+    if (agate && !gate_out && col >= S && col < S + A)                                              // critic's action input
+      v *= ddrl_gate_factor(agate[(size_t)agent * A + col - S], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_BATCH_A, row0 + row, col - S);
     M.x[e] = v;
   }
   __syncthreads();
@@ -361,7 +367,8 @@ net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *_
     const int row = e / dl, col = e - row * dl;
     if (row0 + row < n) {
       float v = M.top[row * ldt + col];
-      if (agate && gate_out) v *= agate[(size_t)agent * A + col];                                  // actor's output
+      if (agate && gate_out)                                                                        // actor's output
+        v *= ddrl_gate_factor(agate[(size_t)agent * A + col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_BATCH_A, row0 + row, col);
       o[(size_t)(row0 + row) * dl + col] = v;
     }
   }
@@ -374,7 +381,7 @@ net_forward_kernel(const NetDesc nd, const float *__restrict__ w, const float *_
 __global__ void __launch_bounds__(256)
 net_forward_wide_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out,
                         float *__restrict__ scratch, int ldw, int n, const float *__restrict__ sgate, int S,
-                        const float *__restrict__ agate, int A, int gate_out) {
+                        const float *__restrict__ agate, int A, int gate_out, const GateMode gm) {
   const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x;
   const int row0 = chunk * DDRL_MB, d0 = nd.d(0), dl = nd.d(nd.L());
   float *buf = scratch + ((size_t)agent * gridDim.x + chunk) * 2 * DDRL_MB * ldw;
@@ -383,8 +390,10 @@ net_forward_wide_kernel(const NetDesc nd, const float *__restrict__ w, const flo
   for (int e = tid; e < DDRL_MB * d0; e += 256) {
     const int row = e / d0, col = e - row * d0;
     float v = row0 + row < n ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
-    if (sgate && col < S) v *= sgate[(size_t)agent * S + col];
-    if (agate && !gate_out && col >= S && col < S + A) v *= agate[(size_t)agent * A + col - S];
+    if (sgate && col < S)
+      v *= ddrl_gate_factor(sgate[(size_t)agent * S + col], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, GS_BATCH_S, row0 + row, col);
+    if (agate && !gate_out && col >= S && col < S + A)
+      v *= ddrl_gate_factor(agate[(size_t)agent * A + col - S], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_BATCH_A, row0 + row, col - S);
     buf[row * ldw + col] = v;
   }
   __syncthreads();
@@ -408,7 +417,8 @@ net_forward_wide_kernel(const NetDesc nd, const float *__restrict__ w, const flo
     const int row = e / dl, col = e - row * dl;
     if (row0 + row < n) {
       float v = top[row * ldw + col];
-      if (agate && gate_out) v *= agate[(size_t)agent * A + col];
+      if (agate && gate_out)
+        v *= ddrl_gate_factor(agate[(size_t)agent * A + col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_BATCH_A, row0 + row, col);
       o[(size_t)(row0 + row) * dl + col] = v;
     }
   }
@@ -421,16 +431,16 @@ extern "C" size_t net_forward_wide_scratch_floats(const NetDesc *nd, int n, int 
 }
 
 extern "C" hipError_t net_forward_wide_launch(const NetDesc *nd, const float *w, const float *X, float *out, float *scratch, int n,
-                                              int G, const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
+                                              int G, const float *sgate, int S, const float *agate, int A, int gate_out, const GateMode *gm, hipStream_t st) {
   int ldw = 4;
   for (int l = 0; l <= nd->L_; ++l) ldw = std::max(ldw, nd->d_[l]);
   hipLaunchKernelGGL(net_forward_wide_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(256), 0, st, *nd, w, X, out, scratch, ldw,
-                     n, sgate, S, agate, A, gate_out);
+                     n, sgate, S, agate, A, gate_out, *gm);
   return hipGetLastError();
 }
 
 extern "C" hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
-                                         const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
+                                         const float *sgate, int S, const float *agate, int A, int gate_out, const GateMode *gm, hipStream_t st) {
   static LdsConfig conf;
   int ldh = 4;
   for (int l = 1; l < nd->L_; ++l) ldh = std::max(ldh, nd->ld_[l]);
@@ -438,6 +448,6 @@ extern "C" hipError_t net_forward_launch(const NetDesc *nd, const float *w, cons
   hipError_t e = ddrl_set_lds(net_forward_kernel, lds, conf);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(net_forward_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out,
-                     n, ldh, sgate, S, agate, A, gate_out);
+                     n, ldh, sgate, S, agate, A, gate_out, *gm);
   return hipGetLastError();
 }

@@ -314,6 +314,7 @@ static int launch_critic(ddrl_pop *h, NfacHost *n, int chunks, int maxlen, int &
       // :266-284: the targets come from the OLD critic's V(s'); then a new net (weights ~N(0, 0.01^2), MLP.hpp:936-944,
       // new solver: zero moments, iter 0) whose V(s) enters the lambda return (:315)
       n->P.value_passes = 2;
+      n->P.gm = next_draw(h, 1);
       HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));
       std::normal_distribution<double> nd01(0.0, 0.01);
       std::vector<double> flat((size_t)h->G * h->net[1].nd.np);
@@ -322,14 +323,17 @@ static int launch_critic(ddrl_pop *h, NfacHost *n, int chunks, int maxlen, int &
       if (rc) return rc;
       HIPCHK(nfac_reinit_launch(&n->P, n->d_fresh, h->stream));
       n->P.value_passes = 1;
+      n->P.gm = next_draw(h, 1);
       HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));
       n->P.value_passes = 3;
       steps = 0;
     } else {
+      n->P.gm = next_draw(h, 1);
       HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));
     }
     HIPCHK(nfac_scan_launch(&n->P, 0, maxlen, h->stream));
     for (int it = 0; it < c.stoch_iter_critic; ++it) {
+      n->P.gm = next_draw(h, 1);
       HIPCHK(nfac_grad_launch(&n->P, 0, chunks, h->stream));
       const int last = fit == c.number_fitted_iteration - 1 && it == c.stoch_iter_critic - 1;
       HIPCHK(nfac_apply_launch(&n->P, 0, steps, last, h->stream));
@@ -372,9 +376,11 @@ extern "C" int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask) {
   int critic_steps = 0;
   if (chunks > 0) {
     if (c.update_critic_first && (rc = launch_critic(h, n, chunks, maxlen, critic_steps))) return rc;   // :430-431
+    n->P.gm = next_draw(h, 1);
     HIPCHK(nfac_values_launch(&n->P, chunks, h->stream));                                               // :460-461
     HIPCHK(nfac_scan_launch(&n->P, 1, maxlen, h->stream));                                              // :464-522
     for (int sia = 0; sia < c.stoch_iter_actor; ++sia) {                                                // :527-572
+      n->P.gm = next_draw(h, 1);
       HIPCHK(nfac_grad_launch(&n->P, 1, chunks, h->stream));
       HIPCHK(nfac_apply_launch(&n->P, 1, sia, 0, h->stream));
     }

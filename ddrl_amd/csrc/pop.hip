@@ -28,12 +28,12 @@ hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap,
                                 const float *s, const float *a, const float *r, const float *s2,
                                 const uint8_t *goal, const uint8_t *mask, hipStream_t st);
 hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, float *actions,
-                        const float *in_gate, const float *out_gate, int G, hipStream_t st);
+                        const float *in_gate, const float *out_gate, const GateMode *gm, int G, hipStream_t st);
 hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
-                              const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
+                              const float *sgate, int S, const float *agate, int A, int gate_out, const GateMode *gm, hipStream_t st);
 size_t net_forward_wide_scratch_floats(const NetDesc *nd, int n, int G);
 hipError_t net_forward_wide_launch(const NetDesc *nd, const float *w, const float *X, float *out, float *scratch, int n, int G,
-                                   const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
+                                   const float *sgate, int S, const float *agate, int A, int gate_out, const GateMode *gm, hipStream_t st);
 hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st);
 hipError_t load_flat_launch(const NetDesc *nd, float *w, const float *flat, int ld, const uint8_t *flag, int G, hipStream_t st);
 hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat, float *nbr,
@@ -557,8 +557,9 @@ extern "C" int ddrl_pop_infer_dev(ddrl_pop_t *h, const float *d_states, float *d
   if (!h || !d_states || !d_actions) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   int rc = set_device(h);
   if (rc) return rc;
+  const GateMode gm = next_draw(h, 1);
   HIPCHK(infer_launch(&h->net[0].nd, h->net[0].st.w, d_states, d_actions, h->gates_on ? h->d_sgate : nullptr,
-                      h->gates_on ? h->d_agate : nullptr, h->G, h->stream));
+                      h->gates_on ? h->d_agate : nullptr, &gm, h->G, h->stream));
   return DDRL_OK;
 }
 
@@ -592,12 +593,13 @@ extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float
   }
   const bool actor = net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET;
   const float *sg = h->gates_on ? h->d_sgate : nullptr, *ag = h->gates_on ? h->d_agate : nullptr;
+  const GateMode gm = next_draw(h, 1);
   hipError_t e = hipMemcpyAsync(dx, x, G * n * d0 * sizeof(float), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess)
     e = wide ? net_forward_wide_launch(&t->nd, net_weights(h, net), dx, dout, dscr, n, h->G, sg, h->cfg.nb_sensors, ag,
-                                       h->cfg.nb_motors, actor ? 1 : 0, h->stream)
+                                       h->cfg.nb_motors, actor ? 1 : 0, &gm, h->stream)
              : net_forward_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, sg, h->cfg.nb_sensors, ag, h->cfg.nb_motors,
-                                  actor ? 1 : 0, h->stream);
+                                  actor ? 1 : 0, &gm, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out, dout, G * n * dl * sizeof(float), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(dx);
@@ -637,6 +639,9 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   h->P.mask = dmask;
   h->P.sgate = h->gates_on ? h->d_sgate : nullptr;
   h->P.agate = h->gates_on ? h->d_agate : nullptr;
+  if (h->gates_on && bernoulli_gates(h) && !fused)
+    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are served by the one-tile update path only (mini_batch_size <= %d, widths <= %d)",
+                     DDRL_MB, DDRL_MAXW);
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
   h->P.nupd = per_launch;
@@ -675,6 +680,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
       h->ev_used++;
       HIPCHK(hipEventRecord(e0, h->stream));
     }
+    h->P.gm = next_draw(h, per_launch);
     if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
     else if (!fused) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
     else if (resident) HIPCHK(ddpg_update_resident_launch(&h->P, h->stream));
@@ -728,6 +734,7 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
   P.mask = dmask;
   P.sgate = h->gates_on ? h->d_sgate : nullptr;
   P.agate = h->gates_on ? h->d_agate : nullptr;
+  if (h->gates_on && bernoulli_gates(h)) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the TD3 update");
   P.sa = h->net[0].st; P.sq = h->net[1].st; P.sq2 = h->net[2].st;
   P.actor_step = actor_step ? h->d_astep : nullptr;
   P.nupd = 1;
@@ -846,6 +853,20 @@ extern "C" int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *act
   }
   if (state_gate) for (size_t i = 0; i < G * S; ++i) state_gate[i] = sg[i];
   if (action_gate) for (size_t i = 0; i < G * A; ++i) action_gate[i] = ag[i];
+  return DDRL_OK;
+}
+
+// DODevMLP's `probabilist` / `scale` keys (DODevMLP.hpp:276-304; per gate kind: st_probabilistic / ac_probabilistic,
+// st_scale / ac_scale): *_bernoulli != 0 selects the per-sample Bernoulli(w) gate (the reference's probabilist = 0),
+// *_scale divides a passed value by w.  seed starts the counter-based draw stream again.
+extern "C" int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  if ((h->wide || h->P.maxchunks > 1 || h->nnets == 3) && (st_bernoulli || ac_bernoulli))
+    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are served by the one-tile DDPG and the NFAC update paths only");
+  h->gm.st_bern = st_bernoulli ? 1 : 0; h->gm.st_scale = st_scale ? 1 : 0;
+  h->gm.ac_bern = ac_bernoulli ? 1 : 0; h->gm.ac_scale = ac_scale ? 1 : 0;
+  h->gm.seed = seed; h->gm.draw = 0;
+  h->P.gm = h->gm;
   return DDRL_OK;
 }
 
@@ -1036,6 +1057,19 @@ int ddrl_pop_checkpoint(ddrl_pop *h, Ckpt &c) {
         (rc = c.dev("gates.action", h->d_agate, G * h->cfg.nb_motors * sizeof(float)))) return rc;
   }
   if (!c.writing) h->gates_on = gates != 0;
+  {
+    int g6[6] = {h->gm.st_bern, h->gm.st_scale, h->gm.ac_bern, h->gm.ac_scale, (int)h->gm.seed, (int)h->gm.draw};
+    for (int i = 0; i < 6; ++i) {
+      char key[24];
+      snprintf(key, sizeof key, "gates.mode%d", i);
+      if ((rc = c.val(key, g6[i]))) return rc;
+    }
+    if (!c.writing) {
+      h->gm.st_bern = g6[0]; h->gm.st_scale = g6[1]; h->gm.ac_bern = g6[2]; h->gm.ac_scale = g6[3];
+      h->gm.seed = (unsigned)g6[4]; h->gm.draw = (unsigned)g6[5];
+      h->P.gm = h->gm;
+    }
+  }
   if (h->nnets == 3 && ((rc = c.dev("td3.noise_seed", h->d_nseed, G * sizeof(uint64_t))) ||
                         (rc = c.dev("td3.noise_count", h->d_ncount, G * sizeof(uint32_t))))) return rc;
   if (h->algo == 1 && (rc = ddrl_nfac_checkpoint(h, c))) return rc;

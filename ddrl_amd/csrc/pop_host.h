@@ -64,6 +64,7 @@ struct ddrl_pop {
   size_t idx_cap = 0;              // ints d_idx holds (grows for multi-update launches)
   // developmental gates (null until ddrl_pop_set_gates)
   float *d_sgate = nullptr, *d_agate = nullptr;
+  GateMode gm = {0, 0, 0, 0, 0u, 0u};              // ddrl_pop_set_gate_mode; gm.draw counts the passes drawn so far
   bool gates_on = false;
   // hyper
   float *d_tau = nullptr, *d_omtau = nullptr, *d_gamma = nullptr;
@@ -261,6 +262,14 @@ static inline int ddrl_pop_wait(ddrl_pop *h) {
   return DDRL_OK;
 }
 #define DDRL_WAIT(h) do { int rc_w_ = ddrl_pop_wait(h); if (rc_w_) return rc_w_; } while (0)
+
+// the gate mode for the next launch, and `passes` draws consumed
+static inline GateMode next_draw(ddrl_pop *h, int passes) {
+  const GateMode g = h->gm;
+  h->gm.draw += (unsigned)passes;
+  return g;
+}
+static inline bool bernoulli_gates(const ddrl_pop *h) { return h->gm.st_bern || h->gm.ac_bern; }
 
 #define DDPG_ONLY(h) do { if ((h)->algo != 0) return ddrl_fail(DDRL_ESTATE, "%s: DDPG populations only", __func__); } while (0)
 

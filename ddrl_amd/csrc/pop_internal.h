@@ -81,6 +81,34 @@ __host__ __device__ constexpr int ddrl_widx(int n, int k, int kp) {
 }
 __host__ __device__ constexpr int ddrl_wsize(int N, int kp) { return ddrl_roundup(N, 16) * kp; }
 
+// Developmental gates (fork layer "Developmental", DODevMLP.hpp:276-304, 378-401; semantics as far as the tree pins them:
+// CaffeUtest.cpp:619-690, 1048-1158).  A gate weight w in [0, 1] per controlled dimension.
+//   probabilist = 1 (bern == 0 here): deterministic -- the stored gate value multiplies the input (the host stores 0 / 1);
+//   probabilist = 0 (bern == 1): per SAMPLE and dimension the input passes with probability w, else 0; with `scale` a
+//   passed value is divided by w (CaffeUtest.cpp:1126-1131).  The draw is a counter-based hash of (seed, draw counter,
+//   agent, site, row, dimension): a backward pass regenerates the mask of its forward pass from the same key, every
+//   layer instance ("site": the actor's and the critic's copies share the WEIGHT blob, DODevMLP.hpp:343-355, not the
+//   masks) and every update draws afresh.  The fork's own generator cannot be matched: parity unpinned beyond the
+//   pass rates the reference tests state.
+struct GateMode { int st_bern, st_scale, ac_bern, ac_scale; unsigned seed, draw; };
+enum { GS_ACTOR_T_S = 0, GS_CRITIC_T_S, GS_ACTOR_T_OUT, GS_CRITIC_T_A, GS_CRITIC_S, GS_CRITIC_A_REPLAY, GS_ACTOR_S, GS_ACTOR_OUT,
+       GS_CRITIC_A, GS_INFER_S, GS_INFER_OUT, GS_BATCH_S, GS_BATCH_A, GS_NFAC_V_S, GS_NFAC_V_S2, GS_NFAC_A_S, GS_NFAC_A_OUT };
+__host__ __device__ inline unsigned ddrl_mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+// the factor a gated value is multiplied by
+__host__ __device__ inline float ddrl_gate_factor(float w, int bern, int scale, unsigned seed, unsigned draw, unsigned agent,
+                                                  unsigned site, unsigned row, unsigned dim) {
+  if (!bern) return w;
+  unsigned h = ddrl_mix32(seed ^ 0x9e3779b9u);
+  h = ddrl_mix32(h ^ draw); h = ddrl_mix32(h ^ (agent * 0x632be5abu + site));
+  h = ddrl_mix32(h ^ (row * 0x27d4eb2fu + dim * 0x165667b1u + 1u));
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+  if (!(u < w)) return 0.f;
+  return scale ? 1.0f / w : 1.0f;
+}
+
 // One MLP's shape and its padded device layout.  Per agent the net is one block of `stride`
 // floats: layer l weights at offw(l) (tile-major, above), bias at offb(l).
 // Two providers with the same accessors: NetDesc (run-time shapes, the generic kernels) and
@@ -164,6 +192,7 @@ struct DdpgParams {
   const float *tau, *omtau, *gamma;   // [G]
   const uint8_t *mask;      // [G] or null
   const float *sgate, *agate;   // developmental gates [G x S], [G x A] (DODevMLP.hpp:376-400), or null
+  GateMode gm;                  // deterministic or Bernoulli gates (above)
   float *loss_out;          // [G]
   float *qt_out;            // [G x B] or null
   float *dact_out;          // [G x B x A] or null
@@ -207,6 +236,7 @@ struct NfacParams {
   const uint8_t *endflag;         // [G x maxT] row is the last transition of its episode
   const float *gamma;             // [G]
   const float *sgate, *agate;     // developmental gates [G x S], [G x A], or null
+  GateMode gm;
   const uint8_t *mask;            // [G] or null
   float *V, *nextV, *tgt, *deltas;   // [G x maxT]
   uint8_t *rowmode;               // [G x maxT] 0: no gradient, 1: target = a, 2: target = pure_a

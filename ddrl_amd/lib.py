@@ -105,6 +105,7 @@ SYMBOLS = [
     ("ddrl_agents_create_td3", _i, [_cp, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
     ("ddrl_pop_set_gates", _i, [_vp, _vp, _vp]),
     ("ddrl_pop_get_gates", _i, [_vp, _vp, _vp]),
+    ("ddrl_pop_set_gate_mode", _i, [_vp, _i, _i, _i, _i, C.c_uint32]),
     ("ddrl_pop_ewc_setup_net", _i, [_vp, _i, _vp]),
     ("ddrl_pop_replay_clear", _i, [_vp, _vp]),
     ("ddrl_pop_update_best_param", _i, [_vp, _vp, _vp]),

@@ -123,6 +123,10 @@ class Population:
         ag = None if action_gate is None else np.ascontiguousarray(action_gate, np.float64).reshape(self.G, self.A)
         _l.check(self.L.ddrl_pop_set_gates(self.h, _p(sg), _p(ag)))
 
+    def set_gate_mode(self, st_bernoulli=False, st_scale=False, ac_bernoulli=False, ac_scale=False, seed=0):
+        """probabilist / scale of the Developmental layer (DODevMLP.hpp:276-304): Bernoulli(w) gates per sample."""
+        _l.check(self.L.ddrl_pop_set_gate_mode(self.h, int(st_bernoulli), int(st_scale), int(ac_bernoulli), int(ac_scale), int(seed)))
+
     def gates(self):
         sg, ag = np.empty((self.G, self.S)), np.empty((self.G, self.A))
         _l.check(self.L.ddrl_pop_get_gates(self.h, _p(sg), _p(ag)))

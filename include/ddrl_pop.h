@@ -188,6 +188,14 @@ int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *q_target
 int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const double *action_gate);
 /* the gates in force, [G x nb_sensors] / [G x nb_motors] (all ones when off); either may be NULL */
 int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate);
+/* The `probabilist` / `scale` parameters of the fork's Developmental layer (DODevMLP.hpp:276-304: st_probabilistic,
+ * ac_probabilistic, st_scale, ac_scale).  *_bernoulli != 0 (the reference's probabilist = 0): per sample and gated
+ * dimension the value passes with probability w (the gate weight), else 0; *_scale divides a passed value by w
+ * (CaffeUtest.cpp:1126-1131).  *_bernoulli = 0 (default; probabilist = 1): the stored gate multiplies.  Every forward
+ * pass of every layer instance draws its own mask, a backward pass re-creates its forward pass's mask (counter-based
+ * generator keyed on seed / pass / agent / layer instance / row / dimension: the fork's generator is unknown, only the
+ * pass rates are pinned).  Served by the one-tile DDPG update, NFAC, infer and forward_batch; DDRL_EINVAL elsewhere. */
+int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed);
 
 /* EWC life-cycle (DODevMLP.hpp:604-758), per agent with mask[g] != 0 */
 int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score /* [G] */, const uint8_t *mask);
@@ -235,8 +243,9 @@ int ddrl_agents_destroy(ddrl_agents_t *h);
  * inform(episode, last_sum_weighted_reward) per agent (:403-574): ewc_setup of the actor before a
  * switch, the new gates on the device, the replay cleared with reset_learning_algo, the critic's
  * ewc_setup with ewc_for_critic = 2 (DeepQNAg.hpp:250-272, OfflineCaclaAg.hpp:225-234); closed action
- * dimensions return the PD set point (neutral_action, :764-775).  heuristic 0 (learned gates) and 2
- * (probabilistic gates) are refused. */
+ * dimensions return the PD set point (neutral_action, :764-775).  heuristic = 2 (st/ac_probabilistic = 0, optional
+ * st/ac_scale, heuristic_linearcoef): Bernoulli gates whose pass probability is episode x coefficient, re-set (after
+ * ewc_setup) at every learning episode (:444-467).  heuristic 0 (learned gates) is refused. */
 /* the population underneath (weights, Adam state, EWC life-cycle); owned by the front end */
 ddrl_pop_t *ddrl_agents_population(ddrl_agents_t *h);
 int ddrl_agents_start_episode(ddrl_agents_t *h, const float *states /* [G x S] */, const uint8_t *learning,

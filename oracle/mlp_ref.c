@@ -18,6 +18,7 @@
 #include <string.h>
 #include <float.h>
 
+#define ORA_ROWQ 16
 struct ora_mlp {
   int L;                       /* number of InnerProduct layers */
   int d[ORA_MAXL + 1];
@@ -31,6 +32,11 @@ struct ora_mlp {
   int B;
   double *act[ORA_MAXL + 1];
   double *in_gate, *out_gate;
+  /* per-row gate factors (Bernoulli developmental gates): a queue of sets, one consumed by each forward; the set of the
+   * last forward stays in force for its backward.  Test plumbing: the masks come from the caller. */
+  int rq_n, rq_B[ORA_ROWQ];
+  double *rq_in[ORA_ROWQ], *rq_out[ORA_ROWQ];
+  double *row_in, *row_out;
   /* EWC (DODevMLP.hpp:803-822) */
   double ewc, ewc_decay, ewc_decay_mult, fisher_beta, fisher_nbr, best_score;
   int best_method, last_update_best;
@@ -67,6 +73,7 @@ ora_mlp *ora_mlp_create(int nlayers, const int *dims, int hidden_act, int out_ac
   return n;
 }
 
+#define ORA_ROWQ_DROP(n) do { free((n)->row_in); free((n)->row_out); (n)->row_in = (n)->row_out = NULL; } while (0)
 static void free_acts(ora_mlp *n) {
   for (int l = 0; l <= n->L; ++l) { free(n->act[l]); n->act[l] = NULL; }
 }
@@ -76,6 +83,8 @@ void ora_mlp_free(ora_mlp *n) {
   free_acts(n);
   free(n->w); free(n->g); free(n->m); free(n->v);
   free(n->in_gate); free(n->out_gate);
+  ORA_ROWQ_DROP(n);
+  for (int i = 0; i < n->rq_n; ++i) { free(n->rq_in[i]); free(n->rq_out[i]); }
   free(n->fisher); free(n->prev_fisher); free(n->best_param); free(n->best_prev);
   free(n);
 }
@@ -99,6 +108,7 @@ ora_mlp *ora_mlp_clone(const ora_mlp *s) {
   n->best_param = dupv(s->best_param, s->np); n->best_prev = dupv(s->best_prev, s->np);
   for (int l = 0; l <= n->L; ++l) n->act[l] = NULL;
   n->B = 0;
+  n->rq_n = 0; n->row_in = n->row_out = NULL;
   return n;
 }
 
@@ -121,6 +131,17 @@ void ora_mlp_set_gates(ora_mlp *n, const double *in_gate, const double *out_gate
   n->in_gate = dupv(in_gate, n->d[0]);
   n->out_gate = dupv(out_gate, n->d[n->L]);
 }
+
+/* queue one set of per-row gate factors [B x d0] / [B x dL] (either may be NULL = ones) for a coming forward */
+int ora_mlp_push_row_gates(ora_mlp *n, const double *in_rows, const double *out_rows, int B) {
+  if (n->rq_n >= ORA_ROWQ) return -1;
+  n->rq_B[n->rq_n] = B;
+  n->rq_in[n->rq_n] = dupv(in_rows, B * n->d[0]);
+  n->rq_out[n->rq_n] = dupv(out_rows, B * n->d[n->L]);
+  n->rq_n++;
+  return 0;
+}
+int ora_mlp_row_gates_pending(const ora_mlp *n) { return n->rq_n; }
 
 /* Caffe ReLULayer::Forward_cpu: max(x,0) + slope*min(x,0); TanHLayer: tanh(x) */
 static double act_fwd(int type, double x) {
@@ -151,9 +172,15 @@ void ora_mlp_forward(ora_mlp *n, const double *x, int B, double *out) {
     n->B = B;
   }
   int d0 = n->d[0];
+  ORA_ROWQ_DROP(n);
+  if (n->rq_n > 0 && n->rq_B[0] == B) {
+    n->row_in = n->rq_in[0]; n->row_out = n->rq_out[0];
+    n->rq_n--;
+    for (int i = 0; i < n->rq_n; ++i) { n->rq_B[i] = n->rq_B[i + 1]; n->rq_in[i] = n->rq_in[i + 1]; n->rq_out[i] = n->rq_out[i + 1]; }
+  }
   for (int i = 0; i < B; ++i)
     for (int k = 0; k < d0; ++k)
-      n->act[0][i * d0 + k] = x[i * d0 + k] * (n->in_gate ? n->in_gate[k] : 1.);
+      n->act[0][i * d0 + k] = x[i * d0 + k] * (n->row_in ? n->row_in[i * d0 + k] : n->in_gate ? n->in_gate[k] : 1.);
   for (int l = 0; l < n->L; ++l) {
     int K = n->d[l], N = n->d[l + 1];
     const double *W = n->w + n->offw[l], *b = n->w + n->offb[l];
@@ -168,9 +195,9 @@ void ora_mlp_forward(ora_mlp *n, const double *x, int B, double *out) {
       }
   }
   int dl = n->d[n->L];
-  if (n->out_gate)
+  if (n->row_out || n->out_gate)
     for (int i = 0; i < B; ++i)
-      for (int o = 0; o < dl; ++o) n->act[n->L][i * dl + o] *= n->out_gate[o];
+      for (int o = 0; o < dl; ++o) n->act[n->L][i * dl + o] *= n->row_out ? n->row_out[i * dl + o] : n->out_gate[o];
   if (out) memcpy(out, n->act[n->L], sizeof(double) * B * dl);
 }
 
@@ -184,8 +211,8 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
   for (int i = 0; i < B * dl; ++i) {
     double d = dout[i];
     double y = n->act[L][i];
-    if (n->out_gate) {
-      double gte = n->out_gate[i % dl];
+    if (n->row_out || n->out_gate) {
+      double gte = n->row_out ? n->row_out[i] : n->out_gate[i % dl];
       d *= gte;
       /* a gated-off output is 0; the activation derivative needs the pre-gate value, which for a
        * 0 gate is irrelevant since d == 0 */
@@ -218,8 +245,8 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
     if (l > 0) {
       for (int i = 0; i < B * K; ++i) dx[i] = act_bwd(n->hidden_act, X[i], dx[i]);
     } else {
-      if (n->in_gate)
-        for (int i = 0; i < B * K; ++i) dx[i] *= n->in_gate[i % K];
+      if (n->row_in || n->in_gate)
+        for (int i = 0; i < B * K; ++i) dx[i] *= n->row_in ? n->row_in[i] : n->in_gate[i % K];
       if (din) memcpy(din, dx, sizeof(double) * B * K);
     }
     free(dy);

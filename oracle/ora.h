@@ -48,6 +48,11 @@ void   ora_mlp_set_iter(ora_mlp *n, int it);
 void   ora_mlp_set_lr(ora_mlp *n, double lr);
 /* input gate mask (developmental state gate) and output gate mask; NULL => all ones */
 void   ora_mlp_set_gates(ora_mlp *n, const double *in_gate, const double *out_gate);
+/* per-row gate factors (Bernoulli developmental gates, CaffeUtest.cpp:1048-1158): queue a set [B x d0] / [B x dL]
+ * (NULL = ones); each forward of batch B consumes the oldest set, which stays in force for that pass's backward and
+ * replaces the per-dimension gates.  Returns 0, or -1 when the queue (16) is full. */
+int    ora_mlp_push_row_gates(ora_mlp *n, const double *in_rows, const double *out_rows, int B);
+int    ora_mlp_row_gates_pending(const ora_mlp *n);
 void   ora_mlp_forward(ora_mlp *n, const double *x, int B, double *out);
 /* backward from a diff on the post-activation output; accumulates param diffs; din may be NULL */
 void   ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din);

@@ -80,6 +80,10 @@ def lib():
     L.ora_mlp_set_iter.argtypes = [vp, C.c_int]
     L.ora_mlp_set_lr.argtypes = [vp, C.c_double]
     L.ora_mlp_set_gates.argtypes = [vp, vp, vp]
+    L.ora_mlp_push_row_gates.argtypes = [vp, vp, vp, C.c_int]
+    L.ora_mlp_push_row_gates.restype = C.c_int
+    L.ora_mlp_row_gates_pending.argtypes = [vp]
+    L.ora_mlp_row_gates_pending.restype = C.c_int
     L.ora_mlp_forward.argtypes = [vp, _dp, C.c_int, _dp]
     L.ora_mlp_backward.argtypes = [vp, _dp, C.c_int, vp]
     L.ora_mlp_zero_grad.argtypes = [vp]
@@ -205,6 +209,15 @@ class Mlp:
 
     def set_adam(self, m, v, it):
         lib().ora_mlp_set_adam(self.h, np.ascontiguousarray(m, np.float64), np.ascontiguousarray(v, np.float64), it)
+
+    def push_row_gates(self, in_rows, out_rows, B):
+        ig = None if in_rows is None else np.ascontiguousarray(in_rows, np.float64).reshape(B, -1)
+        og = None if out_rows is None else np.ascontiguousarray(out_rows, np.float64).reshape(B, -1)
+        if lib().ora_mlp_push_row_gates(self.h, _vp(ig), _vp(og), B):
+            raise RuntimeError("row-gate queue full")
+
+    def row_gates_pending(self):
+        return lib().ora_mlp_row_gates_pending(self.h)
 
     def set_gates(self, in_gate=None, out_gate=None):
         ig = None if in_gate is None else np.ascontiguousarray(in_gate, np.float64)
