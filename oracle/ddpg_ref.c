@@ -22,14 +22,14 @@ ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c) {
   dims[0] = c->S;
   for (int i = 0; i < c->n_hidden_a; ++i) dims[i + 1] = c->hidden_a[i];
   dims[c->n_hidden_a + 1] = c->A;
-  d->ann = ora_mlp_create(c->n_hidden_a + 1, dims, c->hidden_act, c->actor_out_act, c->alpha_a,
-                          c->momentum, -1.);
+  d->ann = ora_mlp_create_bn(c->n_hidden_a + 1, dims, c->hidden_act, c->actor_out_act, c->alpha_a,
+                             c->momentum, -1., c->bn_actor, 0);
   /* critic: DeepQNAg.hpp:224-225 -> MLP critic ctor (MLP.hpp:86-184): input = concat(s, a), out 1 */
   dims[0] = c->S + c->A;
   for (int i = 0; i < c->n_hidden_q; ++i) dims[i + 1] = c->hidden_q[i];
   dims[c->n_hidden_q + 1] = 1;
-  d->qnn = ora_mlp_create(c->n_hidden_q + 1, dims, c->hidden_act, 0, c->alpha_v, c->momentum,
-                          c->decay_v);
+  d->qnn = ora_mlp_create_bn(c->n_hidden_q + 1, dims, c->hidden_act, 0, c->alpha_v, c->momentum,
+                             c->decay_v, c->bn_critic, c->S);
   if (c->ewc >= 0.) {
     ora_mlp_ewc_config(d->ann, c->ewc, c->ewc_decay, c->ewc_fisher_beta, c->ewc_best_method);
     if (c->ewc_for_critic >= 1)  /* DODevMLP::ewc_enabled (DODevMLP.hpp:714-720) */
@@ -37,6 +37,9 @@ ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c) {
   }
   d->ann_target = ora_mlp_clone(d->ann);   /* DeepQNAg.hpp:216-219 */
   d->qnn_target = ora_mlp_clone(d->qnn);   /* DeepQNAg.hpp:231-234 */
+  if (c->test_net) { ora_mlp_set_phase(d->ann_target, 1); ora_mlp_set_phase(d->qnn_target, 1); }
+  d->ann_testing = ora_mlp_clone(d->ann);  /* :221-222 */
+  ora_mlp_set_phase(d->ann_testing, 1);
   if (c->td3) {                            /* TD3Ag.hpp:221-229: a second critic of the same shape and its target */
     d->qnn2 = ora_mlp_create(c->n_hidden_q + 1, dims, c->hidden_act, 0, c->alpha_v, c->momentum, c->decay_v);
     if (c->ewc >= 0. && c->ewc_for_critic >= 1)
@@ -54,6 +57,7 @@ ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c) {
 void ora_ddpg_free(ora_ddpg *d) {
   if (!d) return;
   ora_mlp_free(d->ann); ora_mlp_free(d->qnn); ora_mlp_free(d->ann_target); ora_mlp_free(d->qnn_target);
+  ora_mlp_free(d->ann_testing);
   if (d->qnn2) { ora_mlp_free(d->qnn2); ora_mlp_free(d->qnn_target2); }
   free(d->rep); free(d->last_qt); free(d->last_dact); free(d);
 }
@@ -61,7 +65,7 @@ void ora_ddpg_free(ora_ddpg *d) {
 ora_mlp *ora_ddpg_net(ora_ddpg *d, int which) {
   switch (which) {
     case 0: return d->ann; case 1: return d->qnn; case 2: return d->ann_target; case 3: return d->qnn_target;
-    case 4: return d->qnn2; default: return d->qnn_target2;
+    case 4: return d->qnn2; case 6: return d->ann_testing; default: return d->qnn_target2;
   }
 }
 
@@ -163,6 +167,8 @@ double ora_ddpg_update(ora_ddpg *d, const int *idx_in, int *idx_out) {
   ora_mlp_zero_grad(d->qnn);
   ora_mlp_zero_grad(d->ann);
   ora_mlp_forward(d->ann, all_s, B, pi);
+  if (c->bn_actor != 0 && c->bn_adapt)                  /* :415-420: the actions come from the TEST-phase copy */
+    ora_mlp_forward(d->ann_testing, all_s, B, pi);
   for (int i = 0; i < B; ++i) memcpy(sa + i * (S + A) + S, pi + i * A, sizeof(double) * A);
   ora_mlp_forward(d->qnn, sa, B, NULL);
   for (int i = 0; i < B; ++i) dq[i] = -1.0f;            /* :424-428, NOT divided by B */
@@ -192,6 +198,14 @@ double ora_ddpg_update(ora_ddpg *d, const int *idx_in, int *idx_out) {
   free(idx); free(valid_next); free(all_s); free(all_s2); free(all_a); free(sa); free(next_a);
   free(qt); free(pi); free(dq); free(dsa); free(dact);
   return loss;
+}
+
+void ora_ddpg_sync_testing(ora_ddpg *d) {
+  int np = ora_mlp_nparams(d->ann);
+  double *w = (double *)malloc(sizeof(double) * (np ? np : 1));
+  ora_mlp_get_weights(d->ann, w);
+  ora_mlp_set_weights(d->ann_testing, w);
+  free(w);
 }
 
 /* develop() -> ewc_setup() on the actor, and on the critic when ewc_for_critic == 2

@@ -7,6 +7,7 @@
 struct ora_ddpg {
   ora_ddpg_cfg c;
   ora_mlp *ann, *qnn, *ann_target, *qnn_target;
+  ora_mlp *ann_testing;          /* TEST-phase copy of the actor (DeepQNAg.hpp:221-222) */
   ora_mlp *qnn2, *qnn_target2;   /* TD3Ag.hpp:459 (NULL for DDPG) */
   ora_mt19937 eng;
   /* ring replay */

@@ -34,6 +34,13 @@ struct ora_mlp {
   double *in_gate, *out_gate;
   /* per-row gate factors (Bernoulli developmental gates): a queue of sets, one consumed by each forward; the set of the
    * last forward stays in force for its backward.  Test plumbing: the masks come from the caller. */
+  /* BatchNorm (+ Scale) towers (MLP.hpp:53-79, 978-1021): rank r sits, in place, on act[r] = the input of InnerProduct r
+   * (r < L) or the net's output (r == L, actor "very_all" only).  Parameters live in the flat vector in layer order:
+   * [mean_sum C, var_sum C, factor 1] (lr_mult 0) then Scale's [gamma C, (beta C)]. */
+  int bn_code, bn_rank[ORA_MAXL + 2], bn_c[ORA_MAXL + 2], bn_scale, bn_bias, bn_test;
+  int offbn[ORA_MAXL + 2], offsc[ORA_MAXL + 2];
+  double *xnorm[ORA_MAXL + 2], *bn_den[ORA_MAXL + 2];
+  unsigned char *frozen;       /* lr_mult == 0: untouched by ApplyUpdate */
   int rq_n, rq_B[ORA_ROWQ];
   double *rq_in[ORA_ROWQ], *rq_out[ORA_ROWQ];
   double *row_in, *row_out;
@@ -43,15 +50,38 @@ struct ora_mlp {
   double *fisher, *prev_fisher, *best_param, *best_prev;
 };
 
-ora_mlp *ora_mlp_create(int nlayers, const int *dims, int hidden_act, int out_act,
-                        double lr, int momentum, double decay) {
+/* MLP::convertBN (MLP.hpp:53-79) + where the constructors place the towers: Tower() before every hidden InnerProduct
+ * (rank i-1, :756-758), then rank H on the tower's top (:141, :220), rank H+1 on the actor's output for very_all (:238-240);
+ * the critic's first_except_action normalises the states only, before the concat, and nothing else (:130-134). */
+static void bn_decode(ora_mlp *n, int code, int critic_sensors) {
+  int H = n->L - 1;
+  n->bn_code = code;
+  n->bn_bias = (code & 1) != 0;
+  n->bn_scale = (code & 2) != 0;
+  int b2 = (code & 4) != 0, b3 = (code & 8) != 0, b4 = (code & 16) != 0;
+  for (int r = 0; r <= n->L; ++r) { n->bn_rank[r] = 0; n->bn_c[r] = n->d[r]; }
+  if (b4 && !b2) { n->bn_rank[0] = 1; n->bn_c[0] = critic_sensors; }         /* first_except_action */
+  else if (b4) { for (int r = 0; r <= H; ++r) n->bn_rank[r] = 1; if (critic_sensors == 0) n->bn_rank[n->L] = 1; }   /* very_all */
+  else if (b2 && b3) { for (int r = 0; r <= H; ++r) n->bn_rank[r] = 1; }     /* all */
+  else if (b2) n->bn_rank[0] = 1;                                            /* first */
+  else if (b3) { for (int r = 0; r < H; ++r) n->bn_rank[r] = 1; }            /* all_except_last */
+}
+
+ora_mlp *ora_mlp_create_bn(int nlayers, const int *dims, int hidden_act, int out_act, double lr, int momentum, double decay,
+                           int bn_code, int critic_sensors) {
   ora_mlp *n = (ora_mlp *)calloc(1, sizeof(ora_mlp));
   n->L = nlayers;
   for (int i = 0; i <= nlayers; ++i) n->d[i] = dims[i];
   n->hidden_act = hidden_act;
   n->out_act = out_act;
+  bn_decode(n, bn_code, critic_sensors);
   int off = 0;
-  for (int l = 0; l < nlayers; ++l) {
+  for (int l = 0; l <= nlayers; ++l) {
+    if (n->bn_rank[l]) {
+      n->offbn[l] = off; off += 2 * n->bn_c[l] + 1;
+      n->offsc[l] = off; if (n->bn_scale) off += n->bn_c[l] * (n->bn_bias ? 2 : 1);
+    }
+    if (l == nlayers) break;
     n->offw[l] = off; off += dims[l + 1] * dims[l];
     n->offb[l] = off; off += dims[l + 1];
   }
@@ -60,6 +90,12 @@ ora_mlp *ora_mlp_create(int nlayers, const int *dims, int hidden_act, int out_ac
   n->g = (double *)calloc(off, sizeof(double));
   n->m = (double *)calloc(off, sizeof(double));
   n->v = (double *)calloc(off, sizeof(double));
+  n->frozen = (unsigned char *)calloc(off ? off : 1, 1);
+  for (int l = 0; l <= nlayers; ++l)
+    if (n->bn_rank[l]) {
+      memset(n->frozen + n->offbn[l], 1, 2 * n->bn_c[l] + 1);               /* BatchNormLayer: lr_mult 0 on its three blobs */
+      if (n->bn_scale) for (int c = 0; c < n->bn_c[l]; ++c) n->w[n->offsc[l] + c] = 1.;   /* ScaleLayer: filler 1, bias filler 0 */
+    }
   n->lr = lr;
   /* MLP.hpp:160-173 */
   if (momentum == 0) { n->beta1 = 0.; n->beta2 = 0.999; }
@@ -73,16 +109,35 @@ ora_mlp *ora_mlp_create(int nlayers, const int *dims, int hidden_act, int out_ac
   return n;
 }
 
+ora_mlp *ora_mlp_create(int nlayers, const int *dims, int hidden_act, int out_act,
+                        double lr, int momentum, double decay) {
+  return ora_mlp_create_bn(nlayers, dims, hidden_act, out_act, lr, momentum, decay, 0, 0);
+}
+
+/* the phase of a copy (MLP.hpp:284-338): TEST => use_global_stats on every BatchNorm layer */
+void ora_mlp_set_phase(ora_mlp *n, int test) { n->bn_test = test; }
+int  ora_mlp_bn_layout(const ora_mlp *n, int *rank_on, int *offbn, int *offsc, int *chan) {
+  for (int r = 0; r <= n->L; ++r) { rank_on[r] = n->bn_rank[r]; offbn[r] = n->offbn[r]; offsc[r] = n->offsc[r]; chan[r] = n->bn_c[r]; }
+  return n->bn_scale | (n->bn_bias << 1);
+}
+void ora_mlp_layer_offsets(const ora_mlp *n, int *offw, int *offb) {
+  for (int l = 0; l < n->L; ++l) { offw[l] = n->offw[l]; offb[l] = n->offb[l]; }
+}
+
 #define ORA_ROWQ_DROP(n) do { free((n)->row_in); free((n)->row_out); (n)->row_in = (n)->row_out = NULL; } while (0)
 static void free_acts(ora_mlp *n) {
-  for (int l = 0; l <= n->L; ++l) { free(n->act[l]); n->act[l] = NULL; }
+  for (int l = 0; l <= n->L; ++l) {
+    free(n->act[l]); n->act[l] = NULL;
+    free(n->xnorm[l]); n->xnorm[l] = NULL;
+    free(n->bn_den[l]); n->bn_den[l] = NULL;
+  }
 }
 
 void ora_mlp_free(ora_mlp *n) {
   if (!n) return;
   free_acts(n);
   free(n->w); free(n->g); free(n->m); free(n->v);
-  free(n->in_gate); free(n->out_gate);
+  free(n->in_gate); free(n->out_gate); free(n->frozen);
   ORA_ROWQ_DROP(n);
   for (int i = 0; i < n->rq_n; ++i) { free(n->rq_in[i]); free(n->rq_out[i]); }
   free(n->fisher); free(n->prev_fisher); free(n->best_param); free(n->best_prev);
@@ -106,7 +161,8 @@ ora_mlp *ora_mlp_clone(const ora_mlp *s) {
   n->out_gate = dupv(s->out_gate, s->d[s->L]);
   n->fisher = dupv(s->fisher, s->np); n->prev_fisher = dupv(s->prev_fisher, s->np);
   n->best_param = dupv(s->best_param, s->np); n->best_prev = dupv(s->best_prev, s->np);
-  for (int l = 0; l <= n->L; ++l) n->act[l] = NULL;
+  for (int l = 0; l <= n->L; ++l) { n->act[l] = NULL; n->xnorm[l] = NULL; n->bn_den[l] = NULL; }
+  if (s->frozen) { n->frozen = (unsigned char *)malloc(s->np ? s->np : 1); memcpy(n->frozen, s->frozen, s->np); }
   n->B = 0;
   n->rq_n = 0; n->row_in = n->row_out = NULL;
   return n;
@@ -163,6 +219,74 @@ static double act_bwd(int type, double y, double dy) {
   }
 }
 
+/* Caffe 1.0 BatchNormLayer::Forward_cpu on act[r] in place (eps 1e-5, moving_average_fraction 0.999), then ScaleLayer.
+ * TRAIN: batch mean / biased variance; running sums: factor = factor * maf + 1, mean_sum = mean + maf * mean_sum,
+ * var_sum = B/(B-1) var + maf * var_sum.  TEST (use_global_stats): mean = mean_sum / factor, var = var_sum / factor
+ * (0 when factor == 0). */
+#define ORA_BN_EPS 1e-5
+#define ORA_BN_MAF 0.999
+static void bn_forward(ora_mlp *n, int r, int B) {
+  int D = n->d[r], Cn = n->bn_c[r];
+  double *X = n->act[r];
+  double *P = n->w + n->offbn[r];
+  const double *gam = n->bn_scale ? n->w + n->offsc[r] : NULL;
+  const double *bet = n->bn_scale && n->bn_bias ? n->w + n->offsc[r] + Cn : NULL;
+  free(n->xnorm[r]); free(n->bn_den[r]);
+  n->xnorm[r] = (double *)malloc(sizeof(double) * B * Cn);
+  n->bn_den[r] = (double *)malloc(sizeof(double) * Cn);
+  double sf = 0.;
+  if (n->bn_test) sf = P[2 * Cn] == 0. ? 0. : 1. / P[2 * Cn];
+  else P[2 * Cn] = P[2 * Cn] * ORA_BN_MAF + 1.;
+  for (int c = 0; c < Cn; ++c) {
+    double mean, var;
+    if (n->bn_test) { mean = sf * P[c]; var = sf * P[Cn + c]; }
+    else {
+      mean = 0.;
+      for (int i = 0; i < B; ++i) mean += X[i * D + c];
+      mean /= (double)B;
+      var = 0.;
+      for (int i = 0; i < B; ++i) { double xc = X[i * D + c] - mean; var += xc * xc; }
+      var /= (double)B;
+      double bc = B > 1 ? (double)B / (double)(B - 1) : 1.;
+      P[c] = mean + ORA_BN_MAF * P[c];
+      P[Cn + c] = bc * var + ORA_BN_MAF * P[Cn + c];
+    }
+    double den = sqrt(var + ORA_BN_EPS);
+    n->bn_den[r][c] = den;
+    for (int i = 0; i < B; ++i) {
+      double xn = (X[i * D + c] - mean) / den;
+      n->xnorm[r][i * Cn + c] = xn;
+      X[i * D + c] = gam ? xn * gam[c] + (bet ? bet[c] : 0.) : xn;
+    }
+  }
+}
+
+/* ScaleLayer::Backward_cpu (d gamma = sum dy * x_norm, d beta = sum dy, dx = dy gamma) then BatchNormLayer::Backward_cpu:
+ * TRAIN dx = (dy - mean(dy) - mean(dy y) y) / sqrt(var + eps), TEST dx = dy / sqrt(var + eps).  d [B x D] in place. */
+static void bn_backward(ora_mlp *n, int r, int B, double *d) {
+  int D = n->d[r], Cn = n->bn_c[r];
+  const double *xn = n->xnorm[r];
+  for (int c = 0; c < Cn; ++c) {
+    if (n->bn_scale) {
+      double sg = 0., sb = 0.;
+      for (int i = 0; i < B; ++i) { sg += d[i * D + c] * xn[i * Cn + c]; sb += d[i * D + c]; }
+      n->g[n->offsc[r] + c] += sg;
+      if (n->bn_bias) n->g[n->offsc[r] + Cn + c] += sb;
+      double gam = n->w[n->offsc[r] + c];
+      for (int i = 0; i < B; ++i) d[i * D + c] *= gam;
+    }
+    double den = n->bn_den[r][c];
+    if (n->bn_test) {
+      for (int i = 0; i < B; ++i) d[i * D + c] /= den;
+    } else {
+      double m1 = 0., m2 = 0.;
+      for (int i = 0; i < B; ++i) { m1 += d[i * D + c]; m2 += d[i * D + c] * xn[i * Cn + c]; }
+      m1 /= (double)B; m2 /= (double)B;
+      for (int i = 0; i < B; ++i) d[i * D + c] = (d[i * D + c] - m1 - m2 * xn[i * Cn + c]) / den;
+    }
+  }
+}
+
 /* Net::Forward as used by computeOutBatch / computeOutVFBatch (MLP.hpp:531-579).
  * Layer l: InnerProduct y = x W^T + b (MLP.hpp:926-949) then in-place activation. */
 void ora_mlp_forward(ora_mlp *n, const double *x, int B, double *out) {
@@ -185,6 +309,8 @@ void ora_mlp_forward(ora_mlp *n, const double *x, int B, double *out) {
     int K = n->d[l], N = n->d[l + 1];
     const double *W = n->w + n->offw[l], *b = n->w + n->offb[l];
     int type = (l == n->L - 1) ? n->out_act : n->hidden_act;
+    /* in place on the blob the previous activation wrote (MLP.hpp:756-758): that activation's backward will see these values */
+    if (n->bn_rank[l]) bn_forward(n, l, B);
     const double *X = n->act[l];
     double *Y = n->act[l + 1];
     for (int i = 0; i < B; ++i)
@@ -195,6 +321,7 @@ void ora_mlp_forward(ora_mlp *n, const double *x, int B, double *out) {
       }
   }
   int dl = n->d[n->L];
+  if (n->bn_rank[n->L]) bn_forward(n, n->L, B);
   if (n->row_out || n->out_gate)
     for (int i = 0; i < B; ++i)
       for (int o = 0; o < dl; ++o) n->act[n->L][i * dl + o] *= n->row_out ? n->row_out[i * dl + o] : n->out_gate[o];
@@ -208,6 +335,13 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
   int dl = n->d[L];
   double *dy = (double *)malloc(sizeof(double) * B * dl);
   int type = n->out_act;
+  double *dtop = NULL;
+  if (n->bn_rank[L]) {
+    dtop = (double *)malloc(sizeof(double) * B * dl);
+    memcpy(dtop, dout, sizeof(double) * B * dl);
+    bn_backward(n, L, B, dtop);
+    dout = dtop;
+  }
   for (int i = 0; i < B * dl; ++i) {
     double d = dout[i];
     double y = n->act[L][i];
@@ -220,6 +354,7 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
     }
     dy[i] = act_bwd(type, y, d);
   }
+  free(dtop);
   for (int l = L - 1; l >= 0; --l) {
     int K = n->d[l], N = n->d[l + 1];
     const double *W = n->w + n->offw[l];
@@ -242,6 +377,7 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
         for (int o = 0; o < N; ++o) s += dy[i * N + o] * W[o * K + k];
         dx[i * K + k] = s;
       }
+    if (n->bn_rank[l]) bn_backward(n, l, B, dx);
     if (l > 0) {
       for (int i = 0; i < B * K; ++i) dx[i] = act_bwd(n->hidden_act, X[i], dx[i]);
     } else {
@@ -267,6 +403,7 @@ void ora_mlp_apply_update(ora_mlp *n) {
   int t = n->iter + 1;
   double correction = sqrt(1. - pow(n->beta2, t)) / (1. - pow(n->beta1, t));
   for (int i = 0; i < n->np; ++i) {
+    if (n->frozen && n->frozen[i]) continue;          /* lr_mult 0: local_rate 0, the update value is 0 */
     double g = n->g[i];
     if (!(n->decay < 0) && n->decay != 0.) g += n->decay * n->w[i];
     n->m[i] = (1. - n->beta1) * g + n->beta1 * n->m[i];

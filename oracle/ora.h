@@ -35,6 +35,16 @@ typedef struct ora_mlp ora_mlp;
  * out_act: 0 linear 1 leaky 2 tanh 3 relu.  momentum: 0..3 (MLP.hpp:160-173). decay<0 => off */
 ora_mlp *ora_mlp_create(int nlayers, const int *dims, int hidden_act, int out_act,
                         double lr, int momentum, double decay);
+/* the same with BatchNorm / Scale towers: bn_code = the batch_norm bit-field (MLP.hpp:53-79); critic_sensors = size_sensors
+ * for a critic (its first_except_action variant normalises the states only, and it has no output tower), 0 for an actor.
+ * The flat parameter vector is in the net's layer order: per tower [mean_sum C, var_sum C, factor][gamma C (, beta C)]
+ * before the InnerProduct it feeds (learnable_params(), MLP.hpp:610-676).  Pinned by the consistency properties of
+ * CaffeUtest.cpp:246-386, 1343-1447 (tests/test_oracle_bn.py); BatchNorm/Scale arithmetic = published BVLC Caffe 1.0. */
+ora_mlp *ora_mlp_create_bn(int nlayers, const int *dims, int hidden_act, int out_act, double lr, int momentum, double decay,
+                           int bn_code, int critic_sensors);
+void   ora_mlp_set_phase(ora_mlp *n, int test);       /* copy with ::caffe::Phase::TEST: use_global_stats (MLP.hpp:284-338) */
+int    ora_mlp_bn_layout(const ora_mlp *n, int *rank_on, int *offbn, int *offsc, int *chan);   /* arrays of nlayers + 1; returns scale | bias << 1 */
+void   ora_mlp_layer_offsets(const ora_mlp *n, int *offw, int *offb);
 void   ora_mlp_free(ora_mlp *n);
 ora_mlp *ora_mlp_clone(const ora_mlp *n);
 int    ora_mlp_nparams(const ora_mlp *n);
@@ -86,10 +96,14 @@ typedef struct {
   int ewc_for_critic, ewc_best_method;
   uint32_t seed;                            /* replay sampling engine seed */
   int td3;                                  /* TD3Ag: second critic pair (qnn2, qnn_target2) */
+  int bn_actor, bn_critic;                  /* batch_norm_actor / batch_norm_critic (DeepQNAg.hpp:180-181) */
+  int test_net, bn_adapt;                   /* targets as TEST-phase copies (:216-219, 231-234); :415-420 */
 } ora_ddpg_cfg;
 ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c);
 void   ora_ddpg_free(ora_ddpg *d);
-ora_mlp *ora_ddpg_net(ora_ddpg *d, int which);   /* 0 ann 1 qnn 2 ann_target 3 qnn_target 4 qnn2 5 qnn_target2 (td3) */
+ora_mlp *ora_ddpg_net(ora_ddpg *d, int which);   /* 0 ann 1 qnn 2 ann_target 3 qnn_target 4 qnn2 5 qnn_target2 (td3) 6 ann_testing */
+/* DeepQNAg.hpp:469-472: ann_testing <- every parameter of ann (after the fupd loop) */
+void   ora_ddpg_sync_testing(ora_ddpg *d);
 void   ora_ddpg_insert(ora_ddpg *d, const double *s, const double *a, double r,
                        const double *s2, int goal);          /* ring push, no update */
 int    ora_ddpg_replay_len(const ora_ddpg *d);

@@ -34,6 +34,7 @@ class DdpgCfg(C.Structure):
         ("ewc", C.c_double), ("ewc_decay", C.c_double), ("ewc_fisher_beta", C.c_double),
         ("ewc_for_critic", C.c_int), ("ewc_best_method", C.c_int),
         ("seed", C.c_uint32), ("td3", C.c_int),
+        ("bn_actor", C.c_int), ("bn_critic", C.c_int), ("test_net", C.c_int), ("bn_adapt", C.c_int),
     ]
 
 
@@ -67,6 +68,12 @@ def lib():
     vp = C.c_void_p
     L.ora_mlp_create.restype = vp
     L.ora_mlp_create.argtypes = [C.c_int, _ip, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]
+    L.ora_mlp_create_bn.restype = vp
+    L.ora_mlp_create_bn.argtypes = [C.c_int, _ip, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]
+    L.ora_mlp_set_phase.argtypes = [vp, C.c_int]
+    L.ora_mlp_bn_layout.argtypes = [vp, _ip, _ip, _ip, _ip]
+    L.ora_mlp_layer_offsets.argtypes = [vp, _ip, _ip]
+    L.ora_ddpg_sync_testing.argtypes = [vp]
     L.ora_mlp_free.argtypes = [vp]
     L.ora_mlp_clone.restype = vp
     L.ora_mlp_clone.argtypes = [vp]
@@ -169,12 +176,13 @@ class Mt19937:
 
 
 class Mlp:
-    def __init__(self, dims, hidden_act=1, out_act=0, lr=1e-3, momentum=0, decay=-1.0, _h=None, _own=True):
+    def __init__(self, dims, hidden_act=1, out_act=0, lr=1e-3, momentum=0, decay=-1.0, _h=None, _own=True,
+                 batch_norm=0, critic_sensors=0):
         self.dims = list(dims)
         self._own = _own
         if _h is None:
             d = np.asarray(dims, dtype=np.int32)
-            _h = lib().ora_mlp_create(len(dims) - 1, d, hidden_act, out_act, lr, momentum, decay)
+            _h = lib().ora_mlp_create_bn(len(dims) - 1, d, hidden_act, out_act, lr, momentum, decay, batch_norm, critic_sensors)
         self.h = _h
         self.np = lib().ora_mlp_nparams(self.h)
 
@@ -183,8 +191,24 @@ class Mlp:
             lib().ora_mlp_free(self.h)
             self.h = None
 
-    def clone(self):
-        return Mlp(self.dims, _h=lib().ora_mlp_clone(self.h))
+    def clone(self, test=None):
+        """MLP(const MLP&, copy_solver, phase) (MLP.hpp:284-349); test = True: ::caffe::Phase::TEST"""
+        c = Mlp(self.dims, _h=lib().ora_mlp_clone(self.h))
+        if test is not None:
+            c.set_phase(test)
+        return c
+
+    def set_phase(self, test):
+        lib().ora_mlp_set_phase(self.h, int(bool(test)))
+
+    def bn_layout(self):
+        """-> dict(rank_on, offbn, offsc, chan, scale, bias, offw, offb): where the towers sit in the flat parameter vector"""
+        n = len(self.dims)
+        a = [np.zeros(n, np.int32) for _ in range(4)]
+        flags = lib().ora_mlp_bn_layout(self.h, *a)
+        ow, ob = np.zeros(n - 1, np.int32), np.zeros(n - 1, np.int32)
+        lib().ora_mlp_layer_offsets(self.h, ow, ob)
+        return dict(rank_on=a[0], offbn=a[1], offsc=a[2], chan=a[3], scale=bool(flags & 1), bias=bool(flags & 2), offw=ow, offb=ob)
 
     def set_weights(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
@@ -285,8 +309,10 @@ class Ddpg:
     def __init__(self, S, A, B, hidden_a, hidden_q, replay_cap=10000, hidden_act=1, actor_out_act=2,
                  momentum=0, inverting_grad=True, nstep_return=0, gamma=0.99, tau=0.001, alpha_a=1e-4,
                  alpha_v=1e-3, decay_v=-1.0, ewc=-1.0, ewc_decay=-1.0, ewc_fisher_beta=0.999,
-                 ewc_for_critic=0, ewc_best_method=0, seed=0, td3=False):
+                 ewc_for_critic=0, ewc_best_method=0, seed=0, td3=False, batch_norm_actor=0, batch_norm_critic=0,
+                 test_net=False, bn_adapt=False):
         c = DdpgCfg()
+        c.bn_actor, c.bn_critic, c.test_net, c.bn_adapt = batch_norm_actor, batch_norm_critic, int(test_net), int(bn_adapt)
         c.td3 = int(td3)
         c.S, c.A, c.B, c.replay_cap = S, A, B, replay_cap
         c.n_hidden_a = len(hidden_a); _fill_hidden(c.hidden_a, hidden_a)
@@ -303,6 +329,10 @@ class Ddpg:
         dq = [S + A] + list(hidden_q) + [1]
         self.nets = [Mlp(d, _h=lib().ora_ddpg_net(self.h, i), _own=False)
                      for i, d in enumerate([da, dq, da, dq] + ([dq, dq] if td3 else []))]
+        self.ann_testing = Mlp(da, _h=lib().ora_ddpg_net(self.h, 6), _own=False)
+
+    def sync_testing(self):
+        lib().ora_ddpg_sync_testing(self.h)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -338,10 +368,13 @@ class Ddpg:
     def replay_len(self):
         return lib().ora_ddpg_replay_len(self.h)
 
-    def update(self, idx=None):
+    def update(self, idx=None, sync=True):
+        """one pass of the fupd loop; sync: the ann_testing copy that follows the loop (DeepQNAg.hpp:469-472)"""
         out = np.empty(self.B, dtype=np.int32)
         i = None if idx is None else np.ascontiguousarray(idx, dtype=np.int32)
         loss = lib().ora_ddpg_update(self.h, _vp(i), _vp(out))
+        if sync:
+            self.sync_testing()
         return loss, out
 
     def ewc_setup(self):
