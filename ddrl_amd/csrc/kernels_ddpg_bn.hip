@@ -1,0 +1,234 @@
+// kernels_ddpg_bn.hip -- the DDPG update for nets with BatchNorm / Scale towers (agent.batch_norm_actor / _critic != 0).
+//
+// One 256-thread workgroup per agent runs one pass of the fupd loop of DeepQNAg::end_episode
+// (/root/reference/agent/deepqn/include/DeepQNAg.hpp:343-466) on a minibatch of up to 64 rows, like kernels_ddpg.hip,
+// with the towers of bn_device.h between the InnerProduct passes:
+//   * every TRAIN-phase forward moves its net's running statistics -- the targets' too unless agent.test_net (:216-234), the
+//     critic's twice per update (learn_batch, then Q(s, pi(s)));
+//   * parameter gradients are stored to a per-agent image and applied by a sweep over the agent's block (Adam + L2 on
+//     InnerProducts and Scales, nothing on the statistics: lr_mult 0), the soft updates cover every blob, statistics
+//     included (MLP.hpp:437-452), and run where the reference runs them -- after both nets have stepped;
+//   * agent.bn_adapt (:415-420): the actions fed to the critic come from ann_testing, a TEST-phase copy holding the actor's
+//     parameters as of the end of the previous update call (:469-472).
+// Towers couple the rows of a minibatch, so this path has no chunked variant: mini_batch_size <= 64.
+#include "ddpg_device.h"
+#include "bn_device.h"
+
+struct BnLds {
+  LdsMap M;
+  BnBufs a, q;          // x_norm copies / denominators of the actor's and the critic's towers (hidden tiles shared)
+  float *pa;            // bn_adapt: the TEST-phase copy's actions [64 x lda]
+};
+
+static __host__ __device__ size_t bn_lds_floats(const DdpgParams &P) {
+  const int nh = (P.a.L_ > P.q.L_ ? P.a.L_ : P.q.L_) - 1;
+  const int ldq = P.q.ld_[P.q.L_], lda = P.a.ld_[P.a.L_];
+  size_t f = 2 * (size_t)nh * DDRL_MB * P.ldh;                        // hidden tiles + their x_norm copies
+  f += 2 * (size_t)DDRL_MB * (P.ldxc + P.ldxa) + DDRL_NWAVES * 64;   // input tiles + copies, dump
+  f += (size_t)DDRL_MB * (ldq + 3 * lda + 5);                         // topq, topa, its x_norm copy, pa, per-row scalars
+  f += 2 * (size_t)(DDRL_MAXL + 1) * DDRL_MAXW;                       // denominators
+  return f;
+}
+
+__device__ __forceinline__ BnLds bn_carve(float *p, const DdpgParams &P, int ldq, int lda) {
+  BnLds Z;
+  const int nh = (P.a.L_ > P.q.L_ ? P.a.L_ : P.q.L_) - 1;
+  Z.M = ddpg_carve(p, P.a.L_, P.q.L_, P.ldh, P.ldxc, P.ldxa, ldq, lda);
+  p = (float *)(Z.M.nvalid + DDRL_MB);
+  float *xh = p; p += (size_t)nh * Z.M.hstride;
+  Z.a.h = xh; Z.q.h = xh;
+  Z.q.x0 = p; p += DDRL_MB * P.ldxc;
+  Z.a.x0 = p; p += DDRL_MB * P.ldxa;
+  Z.a.top = p; p += DDRL_MB * lda;
+  Z.q.top = nullptr;                                                  // a critic has no output tower
+  Z.pa = p; p += DDRL_MB * lda;
+  Z.a.den = p; p += (DDRL_MAXL + 1) * DDRL_MAXW;
+  Z.q.den = p;
+  return Z;
+}
+
+// Adam + L2 (+ the soft target update) over the learnable part of an agent's block, gradients from gout
+__device__ __forceinline__ void bn_apply(const NetDesc &nd, const OptCtx o, const float *__restrict__ gout, int tid) {
+  for (int i = tid * 4; i < nd.stride(); i += DDRL_NTHREADS * 4) {
+    bool stats = false;
+    for (int r = 0; r <= nd.L(); ++r)
+      stats = stats || (nd.bn(r) && i >= nd.bn_off(r) && i < nd.bn_off(r) + nd.bn_stats_floats(r));
+    if (stats) continue;
+    OptRegs rg;
+    opt_load4<false, true, false>(o, i, rg);
+    opt_step4<false, true, false>(o, i, *(const f32x4 *)(gout + i), rg, true);
+  }
+}
+// MLP::soft_update over the statistics blobs (they are in params(), MLP.hpp:441-451)
+__device__ __forceinline__ void bn_soft_stats(const NetDesc &nd, const float *__restrict__ w, float *__restrict__ wt, float tau, float omtau, int tid) {
+  for (int r = 0; r <= nd.L(); ++r)
+    if (nd.bn(r))
+      for (int i = nd.bn_off(r) + tid; i < nd.bn_off(r) + nd.bn_stats_floats(r); i += DDRL_NTHREADS) wt[i] = tau * w[i] + omtau * wt[i];
+}
+
+__global__ void __launch_bounds__(DDRL_NTHREADS)
+ddpg_update_bn_kernel(const DdpgParams P) {
+  extern __shared__ __align__(16) float lds[];
+  const int agent = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t live = P.mask ? P.mask[agent] : (uint8_t)1;
+  const int len = P.rep_len[agent], head = P.rep_head[agent];
+  const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
+  if (!live || len < 250 || len < P.B) return;             // DeepQNAg.hpp:338
+  const NetDesc &na = P.a, &nq = P.q;
+  const int S = P.S, A = P.A, B = P.B, ldxc = P.ldxc, ldxa = P.ldxa, ldq = nq.ld(nq.L()), lda = na.ld(na.L());
+  const BnLds Z = bn_carve(lds, P, ldq, lda);
+  const LdsMap &M = Z.M;
+  const int *idx = P.idx + (size_t)agent * B;
+  float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
+  float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
+  float *g_a = P.gpart_a + (size_t)agent * na.stride(), *g_q = P.gpart_q + (size_t)agent * nq.stride();
+  const int tmode = P.test_net ? BN_TEST : BN_TRAIN;
+  auto none = [](int, int, float) {};
+  auto actions_in = [&](const float *src) {                // actions into the critic's input tile
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+      const int row = e / A, col = e - row * A;
+      M.xc[row * ldxc + S + col] = src[row * lda + col];
+    }
+  };
+
+  // ---- a' = ann_target(s'), q' = qnn_target(s', a')  (:379-383) ----
+  if (P.nstep > 0) nstep_horizon(P, S, A, agent, idx, B, len, head, gamma, M, tid);
+  gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);
+  __syncthreads();
+  fwd_net_bn(na, na.L(), w_at, tmode, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);
+  actions_in(M.topa);
+  __syncthreads();
+  fwd_net_bn(nq, nq.L(), w_qt, tmode, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
+  // ---- TD targets (:386-405) ----
+  gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
+  int trow;
+  if (gather_owns_row(tid, trow)) {
+    const float qn = M.topq[trow * ldq];
+    M.yv[trow] = M.dn[trow] != 0.f ? M.rv[trow] : (P.nstep > 0 ? M.nrew[trow] : M.rv[trow]) + gamma * qn;
+  }
+  __syncthreads();
+  if (P.qt_out && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];
+  // ---- critic update: qnn->learn_batch(s, a, y, 1)  (:408; MLP.hpp:468-485) ----
+  fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
+  if (tid < DDRL_MB) {
+    const float df = tid < B ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
+    float sq = df * df;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (tid == 0) P.loss_out[agent] = sq / (float)B * 0.5f;
+    M.topq[tid * ldq] = df / (float)B;
+  }
+  __syncthreads();
+  bwd_net_bn<DW_STORE>(nq, w_q, g_q, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, 0, 0, none, wave, lane, tid);
+  __syncthreads();                                          // (workgroup-scope fence: the sweep reads other threads' gradient stores)
+  {
+    OptCtx oq = make_opt<false>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B, 0);
+    oq.handoff = 0;
+    bn_apply(nq, oq, g_q, tid);
+  }
+  __syncthreads();
+  // ---- actor update (:411-459) ----
+  gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
+  __syncthreads();
+  const bool adapt = P.bn_adapt && na.bn_any();
+  if (adapt) {   // :415-420, the TEST-phase copy's actions (it keeps no activations: the TRAIN pass below rebuilds the tiles)
+    BnBufs nokeep = {nullptr, nullptr, nullptr, nullptr};
+    fwd_net_bn(na, na.L(), const_cast<float *>(P.a_test) + (size_t)agent * na.stride(), BN_TEST, B, 0, M.xa, ldxa, M.hbase, M.hstride,
+               M.topa, lda, nokeep, wave, lane, tid);
+    for (int e = tid; e < DDRL_MB * lda; e += DDRL_NTHREADS) Z.pa[e] = M.topa[e];
+    __syncthreads();
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
+    __syncthreads();
+  }
+  fwd_net_bn(na, na.L(), w_a, BN_TRAIN, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);   // pi = ann(s)
+  const float *acts = adapt ? Z.pa : M.topa;
+  actions_in(acts);
+  __syncthreads();
+  fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);   // Q(s, pi(s)), new critic
+  if (tid < DDRL_MB) M.topq[tid * ldq] = tid < B ? -1.0f : 0.f;            // :424-428, NOT /B
+  __syncthreads();
+  {
+    float *topa = M.topa;
+    const int inverting = P.inverting, out_act = na.out_act();
+    const bool top_tower = na.bn(na.L());
+    float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
+    auto store = [=](int row, int h, float diff) {
+      if (inverting) {                                                   // :432-450, on the actions the critic saw
+        const float out = acts[row * lda + h];
+        if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
+        else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
+      }
+      if (row >= B) diff = 0.f;
+      if (dact_out && row < B) dact_out[row * A + h] = diff;
+      // the actor's output layer: its own blob values feed the activation's backward; under an output tower the tower's
+      // backward comes first (bwd_net_bn)
+      topa[row * lda + h] = top_tower ? diff : act_bwd(out_act, topa[row * lda + h], diff);
+    };
+    bwd_net_bn<DW_NONE>(nq, w_q, nullptr, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, S, A, store, wave, lane, tid);
+  }
+  __syncthreads();
+  // the actor's hidden tiles shared their LDS with the critic pass: rebuild them (same batch statistics, running sums untouched;
+  // the input tile kept its tower's output)
+  fwd_net_bn(na, na.L() - 1, w_a, BN_RECOMPUTE, B, 1, M.xa, ldxa, M.hbase, M.hstride, nullptr, 0, Z.a, wave, lane, tid);
+  bwd_net_bn<DW_STORE>(na, w_a, g_a, false, B, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, 0, 0, none, wave, lane, tid);
+  __syncthreads();
+  {
+    OptCtx oa = make_opt<false>(P, P.sa, na.stride(), agent, tau, omtau, (float)B, 0);
+    oa.handoff = 0;
+    bn_apply(na, oa, g_a, tid);
+  }
+  // ---- soft updates of the statistics (:462-463: after both nets have stepped and the critic's second forward) ----
+  bn_soft_stats(nq, w_q, w_qt, tau, omtau, tid);
+  bn_soft_stats(na, w_a, w_at, tau, omtau, tid);
+  if (tid == 0) { P.sq.iter[agent] += 1; P.sa.iter[agent] += 1; }
+}
+
+extern "C" size_t ddpg_update_bn_lds_bytes(const DdpgParams *P) { return bn_lds_floats(*P) * sizeof(float); }
+
+extern "C" hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st) {
+  static LdsConfig configured;
+  const size_t lds = ddpg_update_bn_lds_bytes(P);
+  hipError_t e = ddrl_set_lds(ddpg_update_bn_kernel, lds, configured);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ddpg_update_bn_kernel, dim3(P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TEST-phase evaluation of n rows per agent through one net with towers (ddrl_pop_forward_batch on such a net: the value
+// a TEST-phase copy returns, MLP.hpp:284-338, 531-579; no state changes)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DDRL_NTHREADS)
+net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out, int n, int ldh) {
+  extern __shared__ __align__(16) float lds[];
+  const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = chunk * DDRL_MB, rows = n - row0 < DDRL_MB ? n - row0 : DDRL_MB;
+  const int d0 = nd.d(0), dl = nd.d(nd.L()), ldx = nd.ld(0), ldt = nd.ld(nd.L());
+  float *hbase = lds, *x = hbase + (size_t)(nd.L() - 1) * DDRL_MB * ldh, *top = x + DDRL_MB * ldx;
+  const float *xin = X + (size_t)agent * n * d0;
+  for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
+    const int row = e / ldx, col = e - row * ldx;
+    x[e] = (row < rows && col < d0) ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
+  }
+  __syncthreads();
+  const BnBufs nokeep = {nullptr, nullptr, nullptr, nullptr};
+  fwd_net_bn(nd, nd.L(), const_cast<float *>(w) + (size_t)agent * nd.stride(), BN_TEST, rows, 0, x, ldx, hbase, DDRL_MB * ldh, top, ldt,
+             nokeep, wave, lane, tid);
+  float *o = out + (size_t)agent * n * dl;
+  for (int e = tid; e < DDRL_MB * dl; e += DDRL_NTHREADS) {
+    const int row = e / dl, col = e - row * dl;
+    if (row < rows) o[(size_t)(row0 + row) * dl + col] = top[row * ldt + col];
+  }
+}
+
+extern "C" hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G, hipStream_t st) {
+  static LdsConfig conf;
+  int ldh = 4;
+  for (int l = 1; l < nd->L_; ++l) ldh = std::max(ldh, nd->ld_[l]);
+  const size_t lds = ((size_t)(nd->L_ - 1) * DDRL_MB * ldh + (size_t)DDRL_MB * (nd->ld_[0] + nd->ld_[nd->L_])) * sizeof(float);
+  hipError_t e = ddrl_set_lds(net_forward_bn_kernel, lds, conf);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(net_forward_bn_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out, n, ldh);
+  return hipGetLastError();
+}

@@ -1,6 +1,6 @@
 // kernels_misc.hip -- replay ring, bit-exact replay index sampling, batch-1 policy inference and
 // the EWC bookkeeping kernels (gfx950).
-#include "mlp_device.h"
+#include "bn_device.h"
 
 // ------------------------------------------------------------------------------------------
 // Replay index sampling: DeepQNAg::sample_transition (DeepQNAg.hpp:275-288) draws
@@ -146,6 +146,7 @@ infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restr
     float x = k < d0 ? states[(size_t)agent * d0 + k] : 0.f;
     if (in_gate && k < d0)
       x *= ddrl_gate_factor(in_gate[(size_t)agent * d0 + k], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, GS_INFER_S, 0, k);
+    if (nd.bn(0) && k < nd.bn_c(0)) x = bn_test_value(nd, wa, 0, k, x);       // ann_testing is a TEST-phase copy (DeepQNAg.hpp:221-222)
     buf[0][k] = x;
   }
   __syncthreads();
@@ -166,6 +167,7 @@ infer_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restr
           s = fmaf(wv[2], xv[2], s); s = fmaf(wv[3], xv[3], s);
         }
         y = act_fwd(act, s + wa[nd.offb(l) + n]);
+        if (nd.bn(l + 1)) y = bn_test_value(nd, wa, l + 1, n, y);
       }
       if (last) {
         if (n < N) {

@@ -27,6 +27,9 @@ hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, 
 hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap, int rowlen, int S, int A,
                                 const float *s, const float *a, const float *r, const float *s2,
                                 const uint8_t *goal, const uint8_t *mask, hipStream_t st);
+hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st);
+size_t ddpg_update_bn_lds_bytes(const DdpgParams *P);
+hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G, hipStream_t st);
 hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, float *actions,
                         const float *in_gate, const float *out_gate, const GateMode *gm, int G, hipStream_t st);
 hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
@@ -107,6 +110,10 @@ static int config_from_ini(const char *path, ddrl_ddpg_config *c, bool td3) {
     c->hidden_layer_type = (int)ini.get_long("agent.hidden_layer_type");
     c->momentum = (int)ini.get_long("agent.momentum");
     if (!td3) c->nstep_return = (int)ini.get_long("agent.nstep_return");
+    // DeepQNAg.hpp:184-185 reads both unconditionally; they only matter with towers, and the tuned ini the tree ships
+    // (agent/deepqn/data/best-ddpg-halfcheetah.ini) predates bn_adapt: absent = false
+    if (ini.has("agent.test_net")) c->test_net = ini.get_bool("agent.test_net");
+    if (ini.has("agent.bn_adapt")) c->bn_adapt = ini.get_bool("agent.bn_adapt");
     if (ini.has("devnn.ewc")) c->ewc = ini.get_double("devnn.ewc");
     if (c->ewc >= 0.) {
       if (ini.has("devnn.ewc_decay")) c->ewc_decay = ini.get_double("devnn.ewc_decay");
@@ -136,7 +143,22 @@ static int validate(const ddrl_ddpg_config *c) {
   if (c->actor_output_layer_type < 0 || c->actor_output_layer_type > 3) return ddrl_fail(DDRL_EINVAL, "actor_output_layer_type not in 0..3");
   if (c->momentum < 0 || c->momentum > 3) return ddrl_fail(DDRL_EINVAL, "momentum not in 0..3");
   if (c->force_more_update < 0 || c->force_more_update >= DDRL_MAXUPD) return ddrl_fail(DDRL_EINVAL, "force_more_update outside 0..%d", DDRL_MAXUPD - 1);
-  if (c->batch_norm_actor || c->batch_norm_critic) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not supported (BatchNorm is outside this round's scope)");
+  if (c->batch_norm_actor || c->batch_norm_critic) {
+    for (int code : {c->batch_norm_actor, c->batch_norm_critic}) {
+      if (code < 0 || code > 31) return ddrl_fail(DDRL_EINVAL, "batch_norm %d outside the 5-bit field of MLP.hpp:53-79", code);
+      if ((code & 1) && !(code & 2)) return ddrl_fail(DDRL_EINVAL, "batch_norm %d: try to scale with bias without scaling", code);   // :71-72
+      if (!(code & 28) && (code & 3)) return ddrl_fail(DDRL_EINVAL, "batch_norm %d: try to scale without bn", code);                 // :73-76
+    }
+    if ((c->batch_norm_actor & 16) && !(c->batch_norm_actor & 4))
+      return ddrl_fail(DDRL_EINVAL, "batch_norm_actor %d: first_except_action is a critic layout", c->batch_norm_actor);
+    if (c->td3) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not served by the TD3 update");
+    if (c->ewc >= 0.) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 with devnn.ewc >= 0 is not supported");
+    if (c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs mini_batch_size <= %d (the towers couple the rows of a minibatch)", DDRL_MB);
+    if (c->force_more_update > 0 && c->bn_adapt) return ddrl_fail(DDRL_EINVAL, "bn_adapt with force_more_update > 0 is not supported");
+    for (int i = 0; i < c->n_hidden_a; ++i) if (c->hidden_unit_a[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs layers of at most %d units", DDRL_MAXW);
+    for (int i = 0; i < c->n_hidden_q; ++i) if (c->hidden_unit_q[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs layers of at most %d units", DDRL_MAXW);
+    if (c->nb_sensors + c->nb_motors > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs nb_sensors + nb_motors <= %d", DDRL_MAXW);
+  }
   if (!(c->alpha_a > 0) || !(c->alpha_v > 0)) return ddrl_fail(DDRL_EINVAL, "alpha <= 0");
   if (c->td3) {
     if (c->policy_freq < 1) return ddrl_fail(DDRL_EINVAL, "policy_freq < 1");
@@ -153,7 +175,7 @@ static int chunk_buffers(ddrl_pop *h) {
   DdpgParams &P = h->P;
   const size_t G = h->G, C = P.maxchunks;
   int rc;
-  if ((C > 1 || h->wide || h->force_chunked) && !P.gpart_a) {
+  if ((C > 1 || h->wide || h->force_chunked || h->bn) && !P.gpart_a) {
     if ((rc = dalloc(h, &P.gpart_a, G * C * h->net[0].nd.stride()))) return rc;
     if ((rc = dalloc(h, &P.gpart_q, G * C * h->net[1].nd.stride()))) return rc;
     if ((rc = dalloc(h, &P.loss_part, G * C))) return rc;
@@ -187,8 +209,10 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "hipStreamCreate failed"));
   const int G = h->G, S = cfg->nb_sensors, A = cfg->nb_motors, B = cfg->mini_batch_size;
   // DeepQNAg.hpp:209-210 (actor) and :224-225 (critic: input = sensors + motors, 1 output, linear)
-  build_desc(h->net[0].nd, S, cfg->hidden_unit_a, cfg->n_hidden_a, A, cfg->hidden_layer_type, cfg->actor_output_layer_type);
-  build_desc(h->net[1].nd, S + A, cfg->hidden_unit_q, cfg->n_hidden_q, 1, cfg->hidden_layer_type, 0);
+  build_desc(h->net[0].nd, S, cfg->hidden_unit_a, cfg->n_hidden_a, A, cfg->hidden_layer_type, cfg->actor_output_layer_type,
+             cfg->batch_norm_actor, 0);
+  build_desc(h->net[1].nd, S + A, cfg->hidden_unit_q, cfg->n_hidden_q, 1, cfg->hidden_layer_type, 0, cfg->batch_norm_critic, S);
+  h->bn = cfg->batch_norm_actor != 0 || cfg->batch_norm_critic != 0;
   const bool ewc = cfg->ewc >= 0.;
   if ((rc = alloc_net(h, h->net[0], ewc))) return bail(rc);
   if ((rc = alloc_net(h, h->net[1], ewc && cfg->ewc_for_critic >= 1))) return bail(rc);   // DODevMLP.hpp:714-720
@@ -256,6 +280,7 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
     for (int k = 0; k < h->nnets; ++k) {
       std::vector<double> flat((size_t)G * h->net[k].nd.np);
       for (auto &x : flat) x = nd01(eng);
+      for (int g = 0; g < G; ++g) fill_bn_defaults(h->net[k].nd, flat.data() + (size_t)g * h->net[k].nd.np);   // statistics 0, gamma 1, beta 0
       if ((rc = upload_flat(h, h->net[k].nd, h->net[k].st.w, flat.data()))) return bail(rc);
       if ((rc = upload_flat(h, h->net[k].nd, h->net[k].st.wt, flat.data()))) return bail(rc);
     }
@@ -293,6 +318,14 @@ extern "C" int ddrl_ddpg_create(const ddrl_ddpg_config *cfg, uint64_t init_seed,
   for (int k = 0; k < 2; ++k)
     for (int l = 1; l < h->net[k].nd.L(); ++l) h->wide = h->wide || h->net[k].nd.d(l) > DDRL_MAXW;
   if ((rc = chunk_buffers(h))) return bail(rc);
+  if (h->bn) {
+    P.test_net = cfg->test_net ? 1 : 0; P.bn_adapt = cfg->bn_adapt ? 1 : 0;
+    if ((rc = dalloc(h, &h->d_atest, (size_t)G * h->net[0].nd.stride()))) return bail(rc);
+    P.a_test = h->d_atest;
+    if ((rc = refresh_testing(h))) return bail(rc);
+    if (ddpg_update_bn_lds_bytes(&P) > 160 * 1024)
+      return bail(ddrl_fail(DDRL_EINVAL, "BatchNorm nets too wide for the LDS-resident update (%zu bytes of LDS)", ddpg_update_bn_lds_bytes(&P)));
+  }
   if (!h->wide && ddpg_update_lds_bytes(&P) > 160 * 1024) return bail(ddrl_fail(DDRL_EINVAL, "network too wide for the LDS-resident kernel (%zu bytes of LDS)", ddpg_update_lds_bytes(&P)));
   if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "sync failed"));
   *out = h;
@@ -435,7 +468,8 @@ extern "C" int ddrl_pop_set_weights(ddrl_pop_t *h, int net, const double *flat) 
   if (!h || !flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   int rc = set_device(h);
   if (rc) return rc;
-  return upload_flat(h, train_net(h, net)->nd, net_weights(h, net), flat);
+  if ((rc = upload_flat(h, train_net(h, net)->nd, net_weights(h, net), flat))) return rc;
+  return h->bn && net == DDRL_NET_ACTOR ? refresh_testing(h) : DDRL_OK;     // the acting copy follows (DeepQNAg.hpp:469-472)
 }
 
 extern "C" int ddrl_pop_get_weights(ddrl_pop_t *h, int net, double *flat) {
@@ -592,11 +626,13 @@ extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float
     return ddrl_fail(DDRL_ENOMEM, "hipMalloc failed");
   }
   const bool actor = net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET;
+  const bool towers = t->nd.bn_any();                      // evaluated as a TEST-phase copy would (kernels_ddpg_bn.hip)
   const float *sg = h->gates_on ? h->d_sgate : nullptr, *ag = h->gates_on ? h->d_agate : nullptr;
   const GateMode gm = next_draw(h, 1);
   hipError_t e = hipMemcpyAsync(dx, x, G * n * d0 * sizeof(float), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess)
-    e = wide ? net_forward_wide_launch(&t->nd, net_weights(h, net), dx, dout, dscr, n, h->G, sg, h->cfg.nb_sensors, ag,
+    e = towers ? net_forward_bn_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, h->stream) :
+        wide ? net_forward_wide_launch(&t->nd, net_weights(h, net), dx, dout, dscr, n, h->G, sg, h->cfg.nb_sensors, ag,
                                        h->cfg.nb_motors, actor ? 1 : 0, &gm, h->stream)
              : net_forward_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, sg, h->cfg.nb_sensors, ag, h->cfg.nb_motors,
                                   actor ? 1 : 0, &gm, h->stream);
@@ -617,7 +653,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, B = h->cfg.mini_batch_size;
-  const bool fused = !h->wide && h->P.maxchunks == 1 && !h->force_chunked;
+  const bool fused = !h->wide && h->P.maxchunks == 1 && !h->force_chunked && !h->bn;   // towers: one update per launch (kernels_ddpg_bn.hip)
   const uint8_t *dmask;
   if ((rc = upload_mask(h, mask, &dmask))) return rc;
   if (idx) {
@@ -681,7 +717,8 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
       HIPCHK(hipEventRecord(e0, h->stream));
     }
     h->P.gm = next_draw(h, per_launch);
-    if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
+    if (h->bn) HIPCHK(ddpg_update_bn_launch(&h->P, h->stream));
+    else if (h->wide) HIPCHK(ddpg_update_wide_launch(&h->P, h->stream));
     else if (!fused) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
     else if (resident) HIPCHK(ddpg_update_resident_launch(&h->P, h->stream));
     else if (pair) HIPCHK(ddpg_update_pair_launch(&h->P, h->stream));
@@ -689,6 +726,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
     if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   }
   h->P.pair = 0;
+  if (h->bn && (rc = refresh_testing(h))) return rc;        // DeepQNAg.hpp:469-472, after the fupd loop
   if (per_launch > 1) h->multi_pending = true;
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
@@ -826,6 +864,7 @@ extern "C" int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const
   int rc = set_device(h);
   if (rc) return rc;
   if (!state_gate && !action_gate) { h->gates_on = false; return DDRL_OK; }
+  if (h->bn) return ddrl_fail(DDRL_EINVAL, "developmental gates on BatchNorm nets are not supported");
   const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
   if (!h->d_sgate) {
     if ((rc = dalloc(h, &h->d_sgate, G * S))) return rc;
@@ -1083,7 +1122,12 @@ static int pop_run_file(ddrl_pop *h, const char *path, bool save) {
   DDRL_WAIT(h);
   Ckpt c;
   if ((rc = c.open(path, save)) || (rc = ddrl_pop_checkpoint(h, c))) return rc;
-  return c.finish();
+  if ((rc = c.finish())) return rc;
+  if (!save && h->bn) {                      // the acting copy equals the actor between update calls (DeepQNAg.hpp:469-472)
+    if ((rc = refresh_testing(h))) return rc;
+    DDRL_WAIT(h);
+  }
+  return DDRL_OK;
 }
 extern "C" int ddrl_pop_save_run(ddrl_pop_t *h, const char *path) { return pop_run_file(h, path, true); }
 extern "C" int ddrl_pop_load_previous_run(ddrl_pop_t *h, const char *path) { return pop_run_file(h, path, false); }

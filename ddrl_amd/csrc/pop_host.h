@@ -84,6 +84,8 @@ struct ddrl_pop {
   int pair_mode = 1;          // 0: never the two-agents-per-workgroup kernel, 1: for launches of >= DDRL_PAIR_MIN_UPD updates, 2: whenever it fits
   bool force_chunked = false;
   bool wide = false;               // some layer is wider than DDRL_MAXW: layer-by-layer update kernels
+  bool bn = false;                 // some net has BatchNorm towers: kernels_ddpg_bn.hip
+  float *d_atest = nullptr;        // ann_testing [G x stride]: the actor's parameters as of the last sync (DeepQNAg.hpp:469-472)
   double beta1 = 0., beta2 = 0.999;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -109,7 +111,10 @@ static int dalloc(ddrl_pop *h, T **p, size_t n, bool zero = true) {
   return DDRL_OK;
 }
 
-static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout, int hidden_act, int out_act) {
+// bn_code: the batch_norm bit-field (MLP.hpp:53-79); critic_sensors: size_sensors for a critic (its first_except_action
+// variant normalises the states only, :130-134, and it has no output tower), 0 for an actor
+static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout, int hidden_act, int out_act,
+                       int bn_code = 0, int critic_sensors = 0) {
   memset(&nd, 0, sizeof(nd));
   nd.L_ = nh + 1;
   nd.d_[0] = d0;
@@ -123,16 +128,43 @@ static void build_desc(NetDesc &nd, int d0, const int *hidden, int nh, int dout,
     np += nd.d_[l + 1] * nd.d_[l] + nd.d_[l + 1];
   }
   for (int i = 0; i <= nd.L_; ++i) nd.ld_[i] = ddrl_ldpad(nd.d_[i]);
+  // towers: convertBN + where the constructors place them (Tower(): rank i - 1 before hidden InnerProduct i, :756-758; rank H
+  // on the tower's top, :141, :220; rank H + 1 on the actor's output for very_all, :238-240)
+  const int H = nh;
+  const bool b2 = bn_code & 4, b3 = bn_code & 8, b4 = bn_code & 16;
+  nd.bn_flags_ = bn_code & 3;
+  for (int r = 0; r <= nd.L_; ++r) nd.bn_c_[r] = nd.d_[r];
+  if (b4 && !b2) { nd.bn_mask_ = 1; nd.bn_c_[0] = critic_sensors; }                          // first_except_action
+  else if (b4) nd.bn_mask_ = ((1 << (H + 1)) - 1) | (critic_sensors == 0 ? 1 << nd.L_ : 0);  // very_all
+  else if (b2 && b3) nd.bn_mask_ = (1 << (H + 1)) - 1;                                       // all
+  else if (b2) nd.bn_mask_ = 1;                                                              // first
+  else if (b3) nd.bn_mask_ = (1 << H) - 1;                                                   // all_except_last
+  for (int r = 0; r <= nd.L_; ++r)
+    if (nd.bn(r)) {
+      nd.bn_off_[r] = off; off += nd.bn_floats(r);
+      np += 2 * nd.bn_c(r) + 1 + (nd.bn_scale() ? nd.bn_c(r) : 0) + (nd.bn_bias() ? nd.bn_c(r) : 0);
+    }
   nd.stride_ = ddrl_roundup(off, 64);
   nd.np = np;
   nd.hidden_act_ = hidden_act;
   nd.out_act_ = out_act;
 }
 
-// flat reference order <-> padded device image of ONE agent
+// flat reference order <-> padded device image of ONE agent.  Reference order = learnable_params() (MLP.hpp:610-676):
+// the net's layers in order, a tower's [mean_sum, var_sum, factor][gamma][beta] ahead of the InnerProduct it feeds.
 static void pack_flat(const NetDesc &nd, const double *flat, float *img) {
   size_t k = 0;
-  for (int l = 0; l < nd.L(); ++l) {
+  for (int l = 0; l <= nd.L(); ++l) {
+    if (nd.bn(l)) {
+      const int C = nd.bn_c(l), C4 = nd.bn_c4(l);
+      float *t = img + nd.bn_off(l);
+      for (int c = 0; c < C; ++c) t[c] = (float)flat[k++];
+      for (int c = 0; c < C; ++c) t[C4 + c] = (float)flat[k++];
+      t[2 * C4] = (float)flat[k++];
+      if (nd.bn_scale()) for (int c = 0; c < C; ++c) t[2 * C4 + 4 + c] = (float)flat[k++];
+      if (nd.bn_bias()) for (int c = 0; c < C; ++c) t[3 * C4 + 4 + c] = (float)flat[k++];
+    }
+    if (l == nd.L()) break;
     for (int n = 0; n < nd.d(l + 1); ++n)
       for (int c = 0; c < nd.d(l); ++c) img[nd.offw(l) + ddrl_widx(n, c, nd.kp(l))] = (float)flat[k++];
     for (int n = 0; n < nd.d(l + 1); ++n) img[nd.offb(l) + n] = (float)flat[k++];
@@ -140,10 +172,34 @@ static void pack_flat(const NetDesc &nd, const double *flat, float *img) {
 }
 static void unpack_flat(const NetDesc &nd, const float *img, double *flat) {
   size_t k = 0;
-  for (int l = 0; l < nd.L(); ++l) {
+  for (int l = 0; l <= nd.L(); ++l) {
+    if (nd.bn(l)) {
+      const int C = nd.bn_c(l), C4 = nd.bn_c4(l);
+      const float *t = img + nd.bn_off(l);
+      for (int c = 0; c < C; ++c) flat[k++] = (double)t[c];
+      for (int c = 0; c < C; ++c) flat[k++] = (double)t[C4 + c];
+      flat[k++] = (double)t[2 * C4];
+      if (nd.bn_scale()) for (int c = 0; c < C; ++c) flat[k++] = (double)t[2 * C4 + 4 + c];
+      if (nd.bn_bias()) for (int c = 0; c < C; ++c) flat[k++] = (double)t[3 * C4 + 4 + c];
+    }
+    if (l == nd.L()) break;
     for (int n = 0; n < nd.d(l + 1); ++n)
       for (int c = 0; c < nd.d(l); ++c) flat[k++] = (double)img[nd.offw(l) + ddrl_widx(n, c, nd.kp(l))];
     for (int n = 0; n < nd.d(l + 1); ++n) flat[k++] = (double)img[nd.offb(l) + n];
+  }
+}
+// the flat positions a fresh net leaves at the fillers' constants instead of N(0, 0.01): tower statistics 0, gamma 1, beta 0
+static void fill_bn_defaults(const NetDesc &nd, double *flat) {
+  size_t k = 0;
+  for (int l = 0; l <= nd.L(); ++l) {
+    if (nd.bn(l)) {
+      const int C = nd.bn_c(l);
+      for (int c = 0; c < 2 * C + 1; ++c) flat[k++] = 0.;
+      if (nd.bn_scale()) for (int c = 0; c < C; ++c) flat[k++] = 1.;
+      if (nd.bn_bias()) for (int c = 0; c < C; ++c) flat[k++] = 0.;
+    }
+    if (l == nd.L()) break;
+    k += (size_t)nd.d(l + 1) * nd.d(l) + nd.d(l + 1);
   }
 }
 
@@ -270,6 +326,13 @@ static inline GateMode next_draw(ddrl_pop *h, int passes) {
   return g;
 }
 static inline bool bernoulli_gates(const ddrl_pop *h) { return h->gm.st_bern || h->gm.ac_bern; }
+
+// ann_testing->copyWeightsFrom(ann->copyWeightsTo) (DeepQNAg.hpp:469-472): every parameter, statistics included
+static inline int refresh_testing(ddrl_pop *h) {
+  if (!h->d_atest) return DDRL_OK;
+  HIPCHK(hipMemcpyAsync(h->d_atest, h->net[0].st.w, (size_t)h->G * h->net[0].nd.stride() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  return DDRL_OK;
+}
 
 #define DDPG_ONLY(h) do { if ((h)->algo != 0) return ddrl_fail(DDRL_ESTATE, "%s: DDPG populations only", __func__); } while (0)
 

@@ -123,6 +123,21 @@ struct NetDesc {
   int stride_;               // floats per agent (multiple of 64 => 256-B aligned blocks)
   int np;                    // logical (flat, reference-order) parameter count
   int hidden_act_, out_act_;
+  // BatchNorm (+ Scale) towers (MLP.hpp:53-79, 978-1021): bit r of bn_mask_ = a tower, in place, on the input of
+  // InnerProduct r (r < L) or on the net's output (r == L: the actor's "very_all").  Tower r of an agent sits in the
+  // agent's block at bn_off_[r]: [mean_sum C4][var_sum C4][factor, 3 pads][gamma C4][beta C4], C4 = roundup(C, 4);
+  // gamma / beta are in use per bn_flags_ (the bit-field's low bits: bit 1 Scale, bit 0 its bias).
+  int bn_mask_, bn_flags_;
+  int bn_c_[DDRL_MAXL + 1], bn_off_[DDRL_MAXL + 1];
+  __host__ __device__ bool bn(int r) const { return (bn_mask_ >> r) & 1; }
+  __host__ __device__ bool bn_any() const { return bn_mask_ != 0; }
+  __host__ __device__ bool bn_scale() const { return (bn_flags_ & 2) != 0; }
+  __host__ __device__ bool bn_bias() const { return (bn_flags_ & 1) != 0; }
+  __host__ __device__ int bn_c(int r) const { return bn_c_[r]; }
+  __host__ __device__ int bn_c4(int r) const { return ddrl_roundup(bn_c_[r], 4); }
+  __host__ __device__ int bn_off(int r) const { return bn_off_[r]; }
+  __host__ __device__ int bn_stats_floats(int r) const { return 2 * bn_c4(r) + 4; }
+  __host__ __device__ int bn_floats(int r) const { return 4 * bn_c4(r) + 4; }
   __host__ __device__ int L() const { return L_; }
   __host__ __device__ int d(int i) const { return d_[i]; }
   __host__ __device__ int kp(int l) const { return kp_[l]; }
@@ -214,6 +229,9 @@ struct DdpgParams {
   int nupd;                 // consecutive updates per launch (>= 1): idx is [G x nupd x B], lr_t [G x nupd]
   int *upd_done;            // [G] updates of this launch an agent has completed (zeroed by the prep kernel)
   int *upd_error;           // [1] raised when a workgroup gave up waiting for its predecessor
+  // BatchNorm nets (kernels_ddpg_bn.hip)
+  int test_net, bn_adapt;   // agent.test_net: the targets run in TEST phase (DeepQNAg.hpp:216-234); agent.bn_adapt (:415-420)
+  const float *a_test;      // [G x stride] ann_testing: the actor's parameters as of the end of the previous update call (:469-472)
   int resident;             // the NetState arrays w, m, v, wt, fisher, fhat, wstar point at ONE agent's block (LDS copy, ddpg_update_resident_kernel): no per-agent offset
   int pair;                 // launched as ddpg_update_pair_kernel (kernels_ddpg_pair.hip): an agent's nupd updates stay in one workgroup
 };

@@ -36,6 +36,7 @@ class DdpgConfigC(C.Structure):
         ("ewc_best_param_method", C.c_int), ("ewc_for_critic", C.c_int),
         ("device", C.c_int),
         ("td3", C.c_int), ("policy_freq", C.c_int), ("policy_noise", C.c_double), ("noise_clip", C.c_double),
+        ("test_net", C.c_int), ("bn_adapt", C.c_int),
     ]
 
 

@@ -63,7 +63,9 @@ typedef struct {
   int    actor_output_layer_type;  /* 0 linear, 1 leaky, 2 tanh, 3 ReLU (MLP.hpp:223-237) */
   int    momentum;                 /* 0..3 -> Adam betas (MLP.hpp:160-173) */
   int    nstep_return;             /* agent.nstep_return (DeepQNAg.hpp:360-373, 394-402) */
-  int    batch_norm_actor, batch_norm_critic;  /* must be 0 this round (BatchNorm out of scope) */
+  int    batch_norm_actor, batch_norm_critic;  /* agent.batch_norm_actor / _critic: the bit-field of MLP.hpp:53-79 (bit 0 Scale bias,
+                                                * bit 1 Scale, bits 2-4 where the towers sit); != 0: mini_batch_size <= 64,
+                                                * widths <= 128, no EWC / gates / TD3 (kernels_ddpg_bn.hip) */
   double gamma;                    /* agent.gamma */
   double tau_soft_update, alpha_a, alpha_v, decay_v;
   /* [devnn] EWC keys (common/include/nn/DODevMLP.hpp:172-190); ewc < 0 disables */
@@ -74,6 +76,9 @@ typedef struct {
   int    td3;
   int    policy_freq;              /* agent.policy_freq: the actor and the targets move every policy_freq-th step */
   double policy_noise, noise_clip; /* agent.policy_noise, agent.noise_clip: target-policy smoothing */
+  /* BatchNorm nets only (DeepQNAg.hpp:184-185, 216-234, 415-420) */
+  int    test_net;                 /* agent.test_net: the target nets are TEST-phase copies (running statistics) */
+  int    bn_adapt;                 /* agent.bn_adapt: the critic scores the actions of ann_testing, the TEST-phase actor copy */
 } ddrl_ddpg_config;
 
 const char *ddrl_last_error(void);

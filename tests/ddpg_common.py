@@ -18,7 +18,7 @@ def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100
               replay_cap=2000, wscale=0.01, seed=0, hidden_act=1, actor_out_act=2, momentum=0,
               inverting_grad=True, decay_v=-1.0, sweep=True, ewc=-1.0, ewc_decay=-1.0,
               ewc_fisher_beta=0.999, ewc_for_critic=0, ewc_best_method=0, force_generic=False, nstep_return=0,
-              goal_prob=0.01, force_wide=False):
+              goal_prob=0.01, force_wide=False, batch_norm_actor=0, batch_norm_critic=0, test_net=False, bn_adapt=False):
     import ddrl_amd
     rng = np.random.RandomState(seed)
     cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=B,
@@ -26,7 +26,9 @@ def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100
                               hidden_layer_type=hidden_act, actor_output_layer_type=actor_out_act,
                               momentum=momentum, inverting_grad=int(inverting_grad), decay_v=decay_v,
                               nstep_return=nstep_return, ewc=ewc, ewc_decay=ewc_decay, ewc_fisher_beta=ewc_fisher_beta,
-                              ewc_for_critic=ewc_for_critic, ewc_best_param_method=ewc_best_method)
+                              ewc_for_critic=ewc_for_critic, ewc_best_param_method=ewc_best_method,
+                              batch_norm_actor=batch_norm_actor, batch_norm_critic=batch_norm_critic, test_net=int(test_net),
+                              bn_adapt=int(bn_adapt))
     pop = ddrl_amd.DdpgPopulation(cfg, init_seed=seed)
     pop.set_option("force_generic", int(force_generic))
     if force_wide:
@@ -53,7 +55,8 @@ def make_pair(ora, G=4, S=18, A=6, B=64, hidden_a=(100, 100), hidden_q=(100, 100
                       nstep_return=nstep_return, gamma=float(np.float32(gamma[g])), tau=float(np.float32(tau[g])),
                       alpha_a=float(np.float32(alpha_a[g])), alpha_v=float(np.float32(alpha_v[g])),
                       decay_v=decay_v, ewc=ewc, ewc_decay=ewc_decay, ewc_fisher_beta=ewc_fisher_beta,
-                      ewc_for_critic=ewc_for_critic, ewc_best_method=ewc_best_method, seed=int(seeds[g]))
+                      ewc_for_critic=ewc_for_critic, ewc_best_method=ewc_best_method, seed=int(seeds[g]),
+                      batch_norm_actor=batch_norm_actor, batch_norm_critic=batch_norm_critic, test_net=test_net, bn_adapt=bn_adapt)
         ag.ann.set_weights(wa[g]); ag.ann_target.set_weights(wa[g])
         ag.qnn.set_weights(wq[g]); ag.qnn_target.set_weights(wq[g])
         rows = synth_transitions(np.random.RandomState(1000 + g + 97 * seed), n_replay, S, A, goal_prob)

@@ -1,0 +1,269 @@
+"""BatchNorm / Scale towers on the device (kernels_ddpg_bn.hip, bn_device.h) against the CPU oracle (oracle/mlp_ref.c, pinned
+by tests/test_oracle_bn.py on the reference's own consistency properties, CaffeUtest.cpp:246-386, 1343-1447).
+
+fp32 against fp64 through a normalisation: the towers divide by sqrt(var + 1e-5), which amplifies rounding where a channel
+barely varies over the minibatch, so the bar here is 1e-4 norm-wise (stated per assertion) instead of the 1e-5 of the plain
+nets; the update is teacher-forced (the oracle restarts every step from the device's state)."""
+import os
+
+import numpy as np
+import pytest
+
+from ddpg_common import BETAS, make_pair, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CODES = [4, 6, 7, 8, 10, 11, 12, 14, 15]
+
+
+def structured_weights(rng, mlp, wscale, G):
+    """[G x np]: InnerProducts ~ N(0, wscale), tower statistics of a net that has seen a few batches, gamma ~ 1, beta ~ 0"""
+    lay = mlp.bn_layout()
+    w = rng.normal(0, wscale, (G, mlp.np))
+    frozen = np.zeros(mlp.np, bool)
+    for r in range(len(mlp.dims)):
+        if not lay["rank_on"][r]:
+            continue
+        C, o = int(lay["chan"][r]), int(lay["offbn"][r])
+        factor = 4.5
+        w[:, o:o + C] = factor * rng.normal(0, 0.3, (G, C))
+        w[:, o + C:o + 2 * C] = factor * rng.uniform(0.2, 1.5, (G, C))
+        w[:, o + 2 * C] = factor
+        frozen[o:o + 2 * C + 1] = True
+        if lay["scale"]:
+            s = int(lay["offsc"][r])
+            w[:, s:s + C] = 1.0 + rng.normal(0, 0.2, (G, C))
+            if lay["bias"]:
+                w[:, s + C:s + 2 * C] = rng.normal(0, 0.2, (G, C))
+    return w.astype(np.float32).astype(np.float64), frozen
+
+
+def make_bn_pair(ora, bna, bnq, G=3, hidden_a=(32, 16), hidden_q=(24, 16), wscale=0.3, seed=0, **kw):
+    pop, agents = make_pair(ora, G=G, hidden_a=hidden_a, hidden_q=hidden_q, seed=seed, batch_norm_actor=bna, batch_norm_critic=bnq,
+                            inverting_grad=kw.pop("inverting_grad", False), **kw)
+    rng = np.random.RandomState(seed + 50)
+    frozen = {}
+    for net in (0, 1):
+        assert pop.num_params(net) == agents[0].nets[net].np
+        w, frozen[net] = structured_weights(rng, agents[0].nets[net], wscale, G)
+        wt = w + (~frozen[net]) * rng.normal(0, 0.02, w.shape)
+        wt = wt.astype(np.float32).astype(np.float64)
+        pop.set_weights(net, w); pop.set_weights(net + 2, wt)
+        for g, a in enumerate(agents):
+            a.nets[net].set_weights(w[g]); a.nets[net + 2].set_weights(wt[g])
+            if net == 0:
+                a.sync_testing()
+    return pop, agents, frozen
+
+
+def sync(pop, agents, testing=None):
+    ws = [pop.weights(n) for n in range(4)]
+    ad = [pop.adam(n) for n in (0, 1)]
+    for g, a in enumerate(agents):
+        for n in range(4):
+            a.nets[n].set_weights(ws[n][g])
+        for n in (0, 1):
+            a.nets[n].set_adam(ad[n][0][g], ad[n][1][g], int(ad[n][2][g]))
+        a.ann_testing.set_weights(ws[0][g] if testing is None else testing[g])
+    return ws
+
+
+def critic_kills_action_gradient(bnq):
+    """A tower directly ahead of the critic's last InnerProduct ("all" / "very_all" layouts): dQ/d(input of that layer) is the
+    same row of W for every sample, and a TRAIN-phase BatchNorm backward maps a per-channel constant to exactly 0
+    (d - mean(d) - mean(d y) y with mean(y) = 0).  The reference's actor then steps on rounding noise; so do we, and
+    neither side's noise can be compared."""
+    return bool(bnq & 4) and bool(bnq & (8 | 16))
+
+
+def check_update(pop, agents, frozen, ws_prev, momentum=0, tol=TOL, actor_noise=False):
+    b1, b2 = BETAS[momentum]
+    for net in (0, 1):
+        m, v, it = pop.adam(net)
+        w = pop.weights(net)
+        for g, a in enumerate(agents):
+            mo, vo, _ = a.nets[net].adam()
+            wo = a.nets[net].weights()
+            fz = frozen[net]
+            if net == 0 and actor_noise:
+                assert not fz.any() or rel_err(w[g][fz], wo[fz]) <= tol, ("statistics", net, g)
+                continue
+            assert rel_err(m[g], mo) <= tol, ("m", net, g, rel_err(m[g], mo))
+            assert rel_err(v[g], vo) <= 2 * tol, ("v", net, g, rel_err(v[g], vo))
+            assert np.all(m[g][fz] == 0) and np.all(v[g][fz] == 0)                    # lr_mult 0: the statistics never step
+            assert not fz.any() or rel_err(w[g][fz], wo[fz]) <= tol, ("statistics", net, g, rel_err(w[g][fz], wo[fz]))
+            t = int(it[g])
+            lr = a.cfg.alpha_a if net == 0 else a.cfg.alpha_v
+            lr_t = float(np.float32(lr)) * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            expect = ws_prev[net][g] - lr_t * m[g] / (np.sqrt(v[g]) + 1e-8)
+            wmax = np.max(np.abs(wo[~fz]))
+            assert np.max(np.abs(w[g][~fz] - expect[~fz])) <= 1e-5 * wmax, ("adam-consistency", net, g)
+            err = np.abs(w[g][~fz] - wo[~fz])
+            assert np.mean(err <= tol * wmax) >= 0.995, ("weights", net, g, np.mean(err <= tol * wmax))
+            # Adam's step is at most lr sqrt((1 - b2^t) / (1 - b2)) <= lr sqrt(t) per entry whatever the gradient (|m| / sqrt(v) <=
+            # 1 / sqrt(1 - b2)): entries whose gradient is rounding-level against the norm may differ by up to twice that
+            assert np.max(err) <= 2 * float(np.float32(lr)) * np.sqrt(t) * 1.001 + tol * wmax, ("step bound", net, g)
+    for net in (2, 3):
+        w = pop.weights(net)
+        for g, a in enumerate(agents):
+            wo = a.nets[net].weights()
+            fz = frozen[net - 2]
+            if not (net == 2 and actor_noise):
+                assert np.mean(np.abs(w[g] - wo) <= tol * np.max(np.abs(wo))) >= 0.995, ("target", net, g)
+            assert not fz.any() or rel_err(w[g][fz], wo[fz]) <= tol, ("target statistics", net, g)
+
+
+@pytest.mark.parametrize("bna,bnq", [(14, 11), (4, 8), (7, 12), (15, 6), (22, 19), (23, 16), (10, 23), (0, 7), (6, 0)])
+def test_ddpg_update_with_towers(ora, bna, bnq):
+    """three teacher-forced updates; 14 / 11 are agent/deepqn/data/best-ddpg-halfcheetah.ini:63-64's, 16+ the first_except_action
+    (critic) and very_all layouts"""
+    G, B = 3, 64
+    pop, agents, frozen = make_bn_pair(ora, bna, bnq, G=G, seed=bna + bnq)
+    noise = critic_kills_action_gradient(bnq)
+    for upd in range(3):
+        ws_prev = sync(pop, agents)
+        idx = np.random.RandomState(5 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        pop.update(idx)
+        last = pop.last()
+        for g, a in enumerate(agents):
+            loss, _ = a.update(idx[g])
+            qt, dact = a.last()
+            assert rel_err(last["q_targets"][g], qt) <= TOL, (upd, g, rel_err(last["q_targets"][g], qt))
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            if noise:      # exactly 0 in exact arithmetic: both are rounding noise far below the critic's weights
+                assert np.max(np.abs(dact)) <= 1e-12 and np.max(np.abs(last["dact"][g])) <= 1e-4
+            else:
+                assert rel_err(last["dact"][g], dact) <= TOL, (upd, g, rel_err(last["dact"][g], dact))
+        check_update(pop, agents, frozen, ws_prev, actor_noise=noise)
+    pop.close()
+
+
+@pytest.mark.parametrize("kw", [dict(test_net=True), dict(bn_adapt=True, inverting_grad=True), dict(B=40, nstep_return=3, momentum=1),
+                                dict(hidden_act=2, actor_out_act=2, decay_v=0.01), dict(hidden_act=3, actor_out_act=0)])
+def test_ddpg_update_variants(ora, kw):
+    """test_net (targets in TEST phase), bn_adapt (the critic scores ann_testing's actions), a ragged minibatch with n-step
+    returns and momentum, tanh / ReLU hidden layers, weight decay on the critic (Scale blobs included)"""
+    G = 2
+    kw = dict(kw)
+    B = kw.get("B", 64)
+    momentum = kw.get("momentum", 0)
+    pop, agents, frozen = make_bn_pair(ora, 14, 11, G=G, seed=3, **kw)
+    testing = pop.weights(0)
+    for upd in range(3):
+        ws_prev = sync(pop, agents, testing)
+        idx = np.random.RandomState(9 + upd).randint(0, 990, (G, B)).astype(np.int32)
+        pop.update(idx)
+        testing = pop.weights(0)                    # ann_testing <- ann after the update call (DeepQNAg.hpp:469-472)
+        last = pop.last()
+        for g, a in enumerate(agents):
+            loss, _ = a.update(idx[g])
+            qt, dact = a.last()
+            assert rel_err(last["q_targets"][g], qt) <= TOL
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            assert rel_err(last["dact"][g], dact) <= TOL
+        check_update(pop, agents, frozen, ws_prev, momentum)
+    pop.close()
+
+
+@pytest.mark.parametrize("bna", CODES + [20, 22, 23])
+def test_inference_is_the_test_phase_copy(ora, bna):
+    """ddrl_pop_infer = ann_testing->computeOut (DeepQNAg.hpp:126), a TEST-phase copy holding the actor's parameters;
+    forward_batch evaluates any net the same way.  Also the fresh net: factor 0 => mean 0, var 0."""
+    import ddrl_amd
+    G, S, A = 3, 18, 6
+    pop, agents, _ = make_bn_pair(ora, bna, 11, G=G, seed=bna)
+    rng = np.random.RandomState(1)
+    st = rng.uniform(-1, 1, (G, S)).astype(np.float32)
+    act = pop.infer(st)
+    x = rng.uniform(-1, 1, (G, 70, S)).astype(np.float32)
+    out = pop.forward_batch(0, x)
+    xq = rng.uniform(-1, 1, (G, 70, S + A)).astype(np.float32)
+    outq = pop.forward_batch(1, xq)
+    for g, a in enumerate(agents):
+        assert rel_err(act[g], a.ann_testing.forward(st[g].astype(np.float64))[0]) <= 1e-5
+        assert rel_err(out[g], a.ann_testing.forward(x[g].astype(np.float64))) <= 1e-5
+        assert rel_err(outq[g], a.qnn.clone(test=True).forward(xq[g].astype(np.float64))) <= 1e-5
+    pop.close()
+    cfg = ddrl_amd.DdpgConfig(n_agents=2, nb_sensors=S, nb_motors=A, hidden_unit_a=(8,), hidden_unit_q=(8,), batch_norm_actor=bna,
+                              actor_output_layer_type=0)
+    fresh = ddrl_amd.DdpgPopulation(cfg, init_seed=1)
+    w = fresh.weights(0)
+    net = ora.Mlp([S, 8, A], 1, 0, 1e-3, batch_norm=bna)
+    assert w.shape[1] == net.np
+    net.set_weights(w[0]); net.set_phase(True)
+    assert rel_err(fresh.infer(st[:2])[0], net.forward(st[0].astype(np.float64))[0]) <= 1e-5
+    lay = net.bn_layout()
+    o, C = int(lay["offbn"][0]), int(lay["chan"][0])
+    assert np.all(w[:, o:o + 2 * C + 1] == 0)
+    if lay["scale"]:
+        assert np.all(w[:, lay["offsc"][0]:lay["offsc"][0] + C] == 1)
+    fresh.close()
+
+
+def test_free_running_and_run_files(ora, tmp_path):
+    """ten free-running updates with device-drawn minibatches stay finite; a saved run restores every blob, statistics and
+    the acting copy included, and both continue identically"""
+    import ddrl_amd
+    G = 2
+    pop, agents, _ = make_bn_pair(ora, 14, 11, G=G, seed=5, bn_adapt=True)
+    for _ in range(5):
+        pop.update()
+    path = os.path.join(str(tmp_path), "run")
+    pop.save_run(path)
+    cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=18, nb_motors=6, hidden_unit_a=(32, 16), hidden_unit_q=(24, 16), replay_memory=2000,
+                              batch_norm_actor=14, batch_norm_critic=11, bn_adapt=1, inverting_grad=0)
+    other = ddrl_amd.DdpgPopulation(cfg, init_seed=99)
+    other.load_previous_run(path)
+    st = np.random.RandomState(2).uniform(-1, 1, (G, 18)).astype(np.float32)
+    assert np.array_equal(pop.infer(st), other.infer(st))
+    for _ in range(5):
+        pop.update(); other.update()
+    for n in range(4):
+        a, b = pop.weights(n), other.weights(n)
+        assert np.all(np.isfinite(a)) and np.array_equal(a, b)
+    pop.close(); other.close()
+
+
+def test_reference_ini_loads_and_updates(tmp_path):
+    """agent/deepqn/data/best-ddpg-halfcheetah.ini:45-72's [agent] section (hidden 20:5:2 / 5:5:2, batch_norm_actor=14,
+    batch_norm_critic=11, alpha 0.3 / 0.1, linear actor output) plus the keys the current DeepQNAg reads that the file
+    predates (momentum, nstep_return, bn_adapt): loads, acts and updates"""
+    import ddrl_amd
+    ini = os.path.join(str(tmp_path), "best.ini")
+    with open(ini, "w") as f:
+        f.write("[agent]\ngamma=0.99\ndecision_each=1\nnoise=0.05\ngaussian_policy=true\nhidden_unit_q=20:5:2\nhidden_unit_a=5:5:2\n"
+                "mini_batch_size=64\nreplay_memory=1000000\ninverting_grad=false\nforce_more_update=0\ntau_soft_update=0.001\n"
+                "alpha_a=0.3\nalpha_v=0.1\ndecay_v=-1\nbatch_norm_actor=14\nbatch_norm_critic=11\ncount_last=true\n"
+                "actor_output_layer_type=0\nhidden_layer_type=1\ntest_net=false\nmomentum=0\nnstep_return=0\n")
+    cfg = ddrl_amd.DdpgConfig.from_ini(ini, n_agents=4, nb_sensors=18, nb_motors=6)
+    assert cfg.get("batch_norm_actor") == 14 and cfg.get("batch_norm_critic") == 11 and cfg.get("bn_adapt") == 0
+    cfg.set("replay_memory", 5000)
+    pop = ddrl_amd.DdpgPopulation(cfg, init_seed=3)
+    # actor: towers on 18, 5, 5, 2 channels with gamma: 3 * 30 + 1 ... ; critic 11: all_except_last with gamma and beta
+    assert pop.num_params(0) == (18 * 5 + 5 + 5 * 5 + 5 + 5 * 2 + 2 + 2 * 6 + 6) + sum(3 * c + 1 for c in (18, 5, 5, 2))
+    assert pop.num_params(1) == (24 * 20 + 20 + 20 * 5 + 5 + 5 * 2 + 2 + 2 + 1) + sum(4 * c + 1 for c in (24, 20, 5))
+    from ddpg_common import synth_transitions
+    for g in range(4):
+        pop.replay_load(g, synth_transitions(np.random.RandomState(g), 600, 18, 6))
+    w0 = [pop.weights(n) for n in range(4)]
+    for _ in range(20):
+        pop.update()
+    for n in range(4):
+        w = pop.weights(n)
+        assert np.all(np.isfinite(w)) and not np.array_equal(w, w0[n])
+    act = pop.infer(np.random.RandomState(1).uniform(-1, 1, (4, 18)).astype(np.float32))
+    assert np.all(np.isfinite(act))
+    with pytest.raises(ddrl_amd.DdrlError, match="gates"):
+        pop.set_gates(np.ones((4, 18)), np.ones((4, 6)))
+    pop.close()
+
+
+@pytest.mark.parametrize("kw,msg", [(dict(mini_batch_size=128), "mini_batch_size"), (dict(ewc=0.5), "ewc"), (dict(batch_norm_actor=1), "without scaling"),
+                                    (dict(batch_norm_actor=3), "without bn"), (dict(batch_norm_actor=18), "critic layout"),
+                                    (dict(hidden_unit_a=(200,)), "128")])
+def test_refusals(kw, msg):
+    import ddrl_amd
+    base = dict(n_agents=1, batch_norm_actor=14, batch_norm_critic=11, replay_memory=500)
+    base.update(kw)
+    with pytest.raises(ddrl_amd.DdrlError, match=msg):
+        ddrl_amd.DdpgPopulation(ddrl_amd.DdpgConfig(**base), init_seed=0)
