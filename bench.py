@@ -215,8 +215,130 @@ def timed_sweep(pop, G, steps, warmup, upl, ewc, barrier):
     return dt, kernel_ms, launches
 
 
+NFAC = dict(S=45, A=17, hidden=(64, 64), T=500, episodes=4, fitted=10, critic_steps=10, actor_steps=10)
+
+
+def nfac_rows(agent, T, S, A):
+    rng = np.random.RandomState(5000 + agent)
+    s = np.clip(np.cumsum(rng.normal(0, 0.1, (T + 1, S)), axis=0), -1, 1)
+    pa = np.tanh(rng.normal(0, 0.7, (T, A))); a = np.clip(pa + rng.normal(0, 0.2, (T, A)), -1, 1)
+    return np.concatenate([s[:-1], pa, a, s[1:], rng.normal(0, 1, (T, 1)), np.zeros((T, 1))], axis=1).astype(np.float32)
+
+
+def nfac_cpu_baseline(seconds, threads):
+    """oracle/nfac_ref.c (fp64 restatement, kind "port") on the same per-agent workload, one agent per thread"""
+    from oracle import oracle as ora
+    ora.lib()
+    c = NFAC
+    ends = [c["T"] * (k + 1) // c["episodes"] for k in range(c["episodes"])]
+    agents, data = [], []
+    for t in range(threads):
+        ag = ora.Nfac(c["S"], c["A"], c["hidden"], c["hidden"], lambda_=0.9, gae=1, number_fitted_iteration=c["fitted"],
+                      stoch_iter_actor=c["actor_steps"], stoch_iter_critic=c["critic_steps"], ewc=100.0, ewc_for_critic=1)
+        rng = np.random.RandomState(2000 + t)
+        ag.ann.set_weights(rng.normal(0, 0.1, ag.ann.np)); ag.vnn.set_weights(rng.normal(0, 0.1, ag.vnn.np))
+        rows = nfac_rows(t, c["T"], c["S"], c["A"]).astype(np.float64)
+        S, A = c["S"], c["A"]
+        data.append((rows[:, :S], rows[:, S:S + A], rows[:, S + A:S + 2 * A], rows[:, S + 2 * A:2 * S + 2 * A], rows[:, 2 * S + 2 * A],
+                     rows[:, 2 * S + 2 * A + 1].astype(np.int32)))
+        agents.append(ag)
+    counts = [0] * threads
+    stop = time.perf_counter() + seconds
+
+    def work(i):
+        while time.perf_counter() < stop:
+            agents[i].update(*data[i], ends)
+            counts[i] += 1
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    return sum(counts) / (time.perf_counter() - t0), sum(counts), time.perf_counter() - t0
+
+
+def nfac_main(args, rank, local_rank, world):
+    """--workload nfac: SURVEY.md 8(d) config 3.  A step = one NFAC(lambda)-V update (OfflineCaclaAg::end_episode's learning
+    branch, OfflineCaclaAg.hpp:423-594) of every agent on this GPU: 10 fitted iterations x 10 full-batch critic steps + 10
+    actor steps on a 500-row trajectory, EWC live on both nets.  Agents are sharded over ranks, no collective."""
+    c = NFAC
+    G = args.agents if args.agents != 1024 else 256
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        ups, n, dt = nfac_cpu_baseline(args.cpu_seconds, threads)
+        cpu = {"value": ups, "unit": "agent updates/s", "cores": threads, "kind": "port", "host_cpu_count": os.cpu_count(),
+               "sample": "%d updates of the same per-agent workload by the fp64 oracle (oracle/nfac_ref.c), one agent per thread on %d threads, %.1f s"
+                         % (n, threads, dt)}
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import ddrl_amd
+    cfg = ddrl_amd.NfacConfig(n_agents=G, nb_sensors=c["S"], nb_motors=c["A"], hidden_unit_a=c["hidden"], hidden_unit_v=c["hidden"],
+                              max_trajectory=512, ewc=100.0, ewc_fisher_beta=0.999, ewc_for_critic=1, ewc_best_param_method=1,
+                              number_fitted_iteration=c["fitted"], stoch_iter_actor=c["actor_steps"], stoch_iter_critic=c["critic_steps"],
+                              device=local_rank)
+    cfg.set("lambda", 0.9); cfg.set("gae", 1)
+    pop = ddrl_amd.NfacPopulation(cfg, init_seed=2000 + rank)
+    ends = [c["T"] * (k + 1) // c["episodes"] for k in range(c["episodes"])]
+
+    def load():
+        for g in range(G):
+            pop.traj_load(g, nfac_rows(rank * G + g, c["T"], c["S"], c["A"]), ends)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pop.sync()
+
+    load(); pop.update()
+    pop.update_best_param(np.ones(G)); pop.ewc_setup()
+    for _ in range(args.warmup):
+        load(); pop.update()
+    steps = args.steps
+    dt = 0.0
+    pop.set_profiling(True); pop.profile_read()
+    for _ in range(steps):                 # the trajectories are consumed by an update: reloading them is outside the timed region
+        load()
+        barrier()
+        t0 = time.perf_counter()
+        pop.update()
+        barrier()
+        dt += time.perf_counter() - t0
+    kernel_ms, launches = pop.profile_read()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    Pw = c["S"] * 64 + 64 * 64 + 64                       # the critic's weights
+    flops_launch = G * c["T"] * (4 * Pw + 2 * (64 * 64 + 64))   # forward + dW over all layers, dX below the first: 2 flop / MAC
+    kavg = kernel_ms * 1e-3 / max(launches, 1)
+    print(json.dumps({
+        "metric": "NFAC(lambda)-V agent updates/sec (config 3)", "value": world * G * steps / dt, "unit": "agent updates/s",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config 3: NFAC(lambda)-V, S=45 A=17, 64x64 nets, %d agents per GPU, T=500 rows in 4 episodes, lambda 0.9 gae, "
+                               "10 fitted iterations x 10 critic steps + 10 actor steps per update, EWC live on both nets" % G,
+                   "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective",
+                   "adam_iterations_per_s": world * G * steps * (c["fitted"] * c["critic_steps"] + c["actor_steps"]) / dt},
+        "roofline": {"bound": "mfma", "achieved": flops_launch / kavg / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": flops_launch / kavg / MFMA_F32_PEAK, "traffic": None,
+                     "kernel": "nfac_grad_kernel<0, ...> (the critic's full-batch gradient: %d of the %d launches of an update)"
+                               % (c["fitted"] * c["critic_steps"], 2 * c["fitted"] * c["critic_steps"] + 2 * c["actor_steps"] + 3 * c["fitted"] + 4),
+                     "kernel_avg_ms": kavg * 1e3, "launches": launches, "algorithmic_flops_per_launch": flops_launch},
+        "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="ddpg", choices=("ddpg", "nfac"),
+                    help="ddpg: BASELINE.json's metric (config 5); nfac: SURVEY.md 8(d) config 3, a second line of the same shape")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=24)
@@ -248,6 +370,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: reporting the world that ran\n" % (args.gpus, world))
+    if args.workload == "nfac" and not args.dry_run:
+        if args.steps == 200 and args.warmup == 24:      # the DDPG defaults: an NFAC step is 220 full-batch Adam iterations
+            args.steps, args.warmup = 10, 2
+        return nfac_main(args, rank, local_rank, world)
     S, A, B = 18, 6, 64
     ha, hq = SIZES[args.size]
     ewc = not args.no_ewc
@@ -342,7 +468,7 @@ def main():
                    "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "ddpg_update_kernel" if max(ha + hq) <= 128 else "wide_* layer kernels, optimiser inside the dW kernels (one update = 45 launches)",
+                     "kernel": ("ddpg_update_pair_kernel" if upl >= 4 and PAIR_MODE else "ddpg_update_kernel") if max(ha + hq) <= 128 else "wide_* layer kernels, optimiser inside the dW kernels (one update = 45 launches)",
                      "kernel_avg_ms": kavg * 1e3, "launches": launches,
                      "updates_per_launch": upl_eff, "algorithmic_bytes_per_launch": byts * G * upl_eff,
                      "algorithmic_bytes_per_agent_update": byts,

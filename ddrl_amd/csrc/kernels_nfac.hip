@@ -16,7 +16,12 @@
 
 struct NfacLds { float *hbase; int hstride; float *x, *top; };
 
-__device__ __forceinline__ NfacLds nfac_carve(float *lds, const NetDesc &nd, int ldh) {
+// compile-time shapes: SURVEY.md 8(d) config 3 (S = 45, A = 17, 64 x 64 hidden, leaky-ReLU, tanh actor output)
+typedef SNet<1, 0, 45, 64, 64, 1> Cfg3Critic;
+typedef SNet<1, 2, 45, 64, 64, 17> Cfg3Actor;
+
+template <class ND>
+__device__ __forceinline__ NfacLds nfac_carve(float *lds, const ND &nd, int ldh) {
   NfacLds M;
   float *p = lds;
   M.hbase = p; M.hstride = DDRL_MB * ldh; p += (nd.L() - 1) * M.hstride;
@@ -42,6 +47,7 @@ __device__ __forceinline__ void load_states(const float *__restrict__ traj, int 
 }
 
 // all_nextV = vnn(s'), all_V = vnn(s)   (OfflineCaclaAg.hpp:266,315 / :460-461)
+template <class ND>
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 nfac_values_kernel(const NfacParams P) {
   extern __shared__ __align__(16) float lds[];
@@ -51,7 +57,7 @@ nfac_values_kernel(const NfacParams P) {
   if (P.mask && !P.mask[agent]) return;
   const int T = P.len[agent], row0 = chunk * DDRL_MB;
   if (row0 >= T) return;
-  const NetDesc &nv = P.v;
+  const auto &nv = Pick<ND>::get(P.v);
   const NfacLds M = nfac_carve(lds, nv, P.ldh);
   const int ldx = nv.ld(0), ldt = nv.ld(nv.L());
   const float *traj = P.traj + (size_t)agent * P.maxT * P.rowlen;
@@ -95,15 +101,20 @@ nfac_scan_kernel(const NfacParams P) {
     sd[li] = (MODE == 0 && P.lambda < 0.f) ? vt : vt - P.V[ro + li];
   }
   __syncthreads();
-  if (scan && tid == 0) {
+  if (scan) {
+    // the recurrence restarts at every episode's last row, so the episodes scan independently: one thread per episode end
+    // walks its episode backwards (the reference's order within an episode, bit for bit)
     const float gl = gamma * P.lambda;
     const uint8_t *ef = P.endflag + ro;
-    float prev = 0.f;
-    for (int li = T - 1; li >= 0; --li) {
-      if (ef[li]) prev = 0.f;
-      const float d = sd[li] + prev;
-      sd[li] = d;
-      prev = gl * d;
+    for (int end = tid; end < T; end += 256) {
+      if (!(ef[end] || end == T - 1)) continue;
+      float prev = 0.f;
+      for (int li = end; li >= 0; --li) {
+        if (li != end && ef[li]) break;
+        const float d = sd[li] + prev;
+        sd[li] = d;
+        prev = gl * d;
+      }
     }
   }
   __syncthreads();
@@ -132,7 +143,7 @@ nfac_scan_kernel(const NfacParams P) {
 // One chunk of one full-batch gradient.  MODE 0: critic, EuclideanLoss against tgt (MLP.hpp:950-957:
 // d yhat = (yhat - y) / T).  MODE 1: actor, top diff = -(target - pi(s)) on the selected rows with
 // optional inverting gradient (OfflineCaclaAg.hpp:531-566), no 1/T.
-template <int MODE>
+template <int MODE, class ND>
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
 nfac_grad_kernel(const NfacParams P) {
   extern __shared__ __align__(16) float lds[];
@@ -143,7 +154,7 @@ nfac_grad_kernel(const NfacParams P) {
   const int T = P.len[agent], row0 = chunk * DDRL_MB;
   if (row0 >= T) return;
   if (MODE == 1 && P.n_pos[agent] <= 0) return;
-  const NetDesc &nd = MODE == 0 ? P.v : P.a;
+  const auto &nd = Pick<ND>::get(MODE == 0 ? P.v : P.a);
   const NetState &st = MODE == 0 ? P.sv : P.sa;
   const NfacLds M = nfac_carve(lds, nd, P.ldh);
   const int ldx = nd.ld(0), ldt = nd.ld(nd.L());
@@ -282,13 +293,18 @@ extern "C" size_t nfac_lds_need(const NfacParams *P) {
   return std::max(nfac_lds_bytes(P->a, P->ldh), nfac_lds_bytes(P->v, P->ldh));
 }
 
-extern "C" hipError_t nfac_values_launch(const NfacParams *P, int chunks, hipStream_t st) {
+template <class ND>
+static hipError_t values_launch_t(const NfacParams *P, int chunks, size_t lds, hipStream_t st) {
   static LdsConfig conf;
-  const size_t lds = nfac_lds_bytes(P->v, P->ldh);
-  hipError_t e = ddrl_set_lds(nfac_values_kernel, lds, conf);
+  hipError_t e = ddrl_set_lds(nfac_values_kernel<ND>, lds, conf);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(nfac_values_kernel, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  hipLaunchKernelGGL(nfac_values_kernel<ND>, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
+}
+extern "C" hipError_t nfac_values_launch(const NfacParams *P, int chunks, hipStream_t st) {
+  const size_t lds = nfac_lds_bytes(P->v, P->ldh);
+  if (!P->generic && Cfg3Critic::matches(P->v)) return values_launch_t<Cfg3Critic>(P, chunks, lds, st);
+  return values_launch_t<NetDesc>(P, chunks, lds, st);
 }
 
 extern "C" hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen, hipStream_t st) {
@@ -301,14 +317,22 @@ extern "C" hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen
   return hipGetLastError();
 }
 
-extern "C" hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, hipStream_t st) {
-  static LdsConfig conf0, conf1;
-  const size_t lds = nfac_lds_bytes(mode == 0 ? P->v : P->a, P->ldh);
-  hipError_t e = mode == 0 ? ddrl_set_lds(nfac_grad_kernel<0>, lds, conf0) : ddrl_set_lds(nfac_grad_kernel<1>, lds, conf1);
+template <int MODE, class ND>
+static hipError_t grad_launch_t(const NfacParams *P, int chunks, size_t lds, hipStream_t st) {
+  static LdsConfig conf;
+  hipError_t e = ddrl_set_lds(nfac_grad_kernel<MODE, ND>, lds, conf);
   if (e != hipSuccess) return e;
-  if (mode == 0) hipLaunchKernelGGL(nfac_grad_kernel<0>, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
-  else hipLaunchKernelGGL(nfac_grad_kernel<1>, dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  hipLaunchKernelGGL((nfac_grad_kernel<MODE, ND>), dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
+}
+extern "C" hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, hipStream_t st) {
+  const size_t lds = nfac_lds_bytes(mode == 0 ? P->v : P->a, P->ldh);
+  if (mode == 0) {
+    if (!P->generic && Cfg3Critic::matches(P->v)) return grad_launch_t<0, Cfg3Critic>(P, chunks, lds, st);
+    return grad_launch_t<0, NetDesc>(P, chunks, lds, st);
+  }
+  if (!P->generic && Cfg3Actor::matches(P->a)) return grad_launch_t<1, Cfg3Actor>(P, chunks, lds, st);
+  return grad_launch_t<1, NetDesc>(P, chunks, lds, st);
 }
 
 extern "C" hipError_t nfac_apply_launch(const NfacParams *P, int mode, int iter_add, int last, hipStream_t st) {

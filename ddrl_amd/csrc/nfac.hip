@@ -334,7 +334,11 @@ static int launch_critic(ddrl_pop *h, NfacHost *n, int chunks, int maxlen, int &
     HIPCHK(nfac_scan_launch(&n->P, 0, maxlen, h->stream));
     for (int it = 0; it < c.stoch_iter_critic; ++it) {
       n->P.gm = next_draw(h, 1);
+      hipEvent_t pe;                                   // profiling on: the critic's gradient launches are the ones timed
+      int prc = prof_begin(h, &pe);
+      if (prc) return prc;
       HIPCHK(nfac_grad_launch(&n->P, 0, chunks, h->stream));
+      if ((prc = prof_end(h, pe))) return prc;
       const int last = fit == c.number_fitted_iteration - 1 && it == c.stoch_iter_critic - 1;
       HIPCHK(nfac_apply_launch(&n->P, 0, steps, last, h->stream));
       ++steps;
@@ -368,6 +372,7 @@ extern "C" int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask) {
   HIPCHK(hipMemcpyAsync(n->d_endflag, flags.data(), flags.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(n->d_len, n->h_len.data(), G * sizeof(int), hipMemcpyHostToDevice, h->stream));
   n->P.mask = dmask;
+  n->P.generic = h->force_generic ? 1 : 0;
   n->P.sgate = h->gates_on ? h->d_sgate : nullptr;
   n->P.agate = h->gates_on ? h->d_agate : nullptr;
   n->P.sa = h->net[0].st;

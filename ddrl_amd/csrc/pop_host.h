@@ -334,5 +334,25 @@ static inline int refresh_testing(ddrl_pop *h) {
   return DDRL_OK;
 }
 
+// measurement hook (ddrl_pop_set_profiling): a HIP event pair around one launch on the handle's stream
+static inline int prof_begin(ddrl_pop *h, hipEvent_t *e1) {
+  *e1 = nullptr;
+  if (!h->profiling) return DDRL_OK;
+  hipEvent_t e0 = nullptr;
+  if (h->ev_used == h->ev_pool.size()) {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(e1));
+    h->ev_pool.emplace_back(e0, *e1);
+  }
+  e0 = h->ev_pool[h->ev_used].first; *e1 = h->ev_pool[h->ev_used].second;
+  h->ev_used++;
+  HIPCHK(hipEventRecord(e0, h->stream));
+  return DDRL_OK;
+}
+static inline int prof_end(ddrl_pop *h, hipEvent_t e1) {
+  if (e1) HIPCHK(hipEventRecord(e1, h->stream));
+  return DDRL_OK;
+}
+
 #define DDPG_ONLY(h) do { if ((h)->algo != 0) return ddrl_fail(DDRL_ESTATE, "%s: DDPG populations only", __func__); } while (0)
 

@@ -246,6 +246,7 @@ struct NfacParams {
   int corrected;                  // agent.corrected_update_ac: actor diff = -(target - pi) * corr_factor, no inverting gradient
   float corr_factor;
   int value_passes;               // nfac_values_kernel: bit 0 = V(s), bit 1 = V(s')
+  int generic;                    // 1: never the compile-time-shape instantiations (option "force_generic")
   float lambda;
   float beta1, beta2, omb1, omb2, eps, fisher_beta;
   double dbeta1, dbeta2;

@@ -172,6 +172,9 @@ class Population:
     def load_previous_run(self, path):
         _l.check(self.L.ddrl_pop_load_previous_run(self.h, str(path).encode()))
 
+    def set_option(self, key, value):
+        _l.check(self.L.ddrl_pop_set_option(self.h, key.encode(), int(value)))
+
     def set_profiling(self, on=True):
         _l.check(self.L.ddrl_pop_set_profiling(self.h, int(on)))
 
@@ -234,8 +237,6 @@ class DdpgPopulation(Population):
         _l.check(self.L.ddrl_pop_ddpg_last(self.h, _p(idx), _p(loss), _p(qt), _p(da)))
         return dict(idx=idx, loss=loss, q_targets=qt, dact=da)
 
-    def set_option(self, key, value):
-        _l.check(self.L.ddrl_pop_set_option(self.h, key.encode(), int(value)))
 
 
 class Td3Population(DdpgPopulation):

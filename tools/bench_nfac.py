@@ -17,6 +17,8 @@ cfg = ddrl_amd.NfacConfig(n_agents=G, nb_sensors=S, nb_motors=A, hidden_unit_a=(
                           max_trajectory=512, ewc=100.0, ewc_fisher_beta=0.999, ewc_for_critic=1, ewc_best_param_method=1)
 cfg.set("lambda", 0.9); cfg.set("gae", 1)
 pop = ddrl_amd.NfacPopulation(cfg, init_seed=1)
+if len(sys.argv) > 3 and sys.argv[3] == "generic":
+    pop.set_option("force_generic", 1)
 rng = np.random.RandomState(0)
 
 
