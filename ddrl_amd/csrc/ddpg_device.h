@@ -35,7 +35,7 @@ struct LdsMap {
 // reward / goal into rv / dn.
 __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, int ldxc, int ldxa, int agent,
                                             const int *__restrict__ idx, int B, int head, bool next,
-                                            const LdsMap &M, int tid, unsigned draw = 0) {
+                                            const LdsMap &M, int tid, int u = 0) {
   // DDRL_NTHREADS / 64 threads per row, each with its own column residue: a thread reads idx[row] once
   // and its row loads are independent of each other, so the whole gather costs two memory round trips
   // (index, then row) instead of two per element
@@ -60,8 +60,9 @@ __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, i
     // developmental gates on the state inputs of both nets (each net's own layer instance: its own Bernoulli draw) and on
     // the critic's action input
     float vc = v, va = v;
-    if (live) {
+    if (live && (sg || ag)) {
       const GateMode &gm = P.gm;
+      const unsigned draw = gm.draw + (unsigned)u;
       if (sg && col < S) {
         vc *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_CRITIC_T_S : GS_CRITIC_S, row, col);
         va *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_ACTOR_T_S : GS_ACTOR_S, row, col);

@@ -16,7 +16,6 @@ struct UpdView {
   int S, A, B, ldxc, ldxa, ldq, lda, tid, lane, wave;
   LdsMap M;
   const float *agate;
-  GateMode gm; unsigned draw; int agent;
   const float *w_a, *w_at, *w_q, *w_qt;
   long long *stamps;
   bool diag;
@@ -37,7 +36,6 @@ __device__ __forceinline__ UpdView<NA, NQ> upd_view(const DdpgParams &P, float *
   V.M = ddpg_carve(lds, na.L(), nq.L(), P.ldh, V.ldxc, V.ldxa, V.ldq, V.lda);
   V.stamps = P.stamps ? P.stamps + (size_t)agent * 16 : nullptr;
   V.agate = P.agate ? P.agate + (size_t)agent * V.A : nullptr;
-  V.gm = P.gm; V.draw = P.gm.draw + (unsigned)u; V.agent = agent;
   const size_t sa = P.resident ? 0 : (size_t)agent;      // resident: the state arrays are one agent's LDS copy
   V.w_a = P.sa.w + sa * na.stride(); V.w_at = P.sa.wt + sa * na.stride();
   V.w_q = P.sq.w + sa * nq.stride(); V.w_qt = P.sq.wt + sa * nq.stride();
@@ -59,16 +57,19 @@ __device__ __forceinline__ UpdView<NA, NQ> upd_view(const DdpgParams &P, float *
 #define STAMP(i) do { if (V.stamps && V.tid == 0) V.stamps[i] = clock64(); } while (0)
 
 // the actor's actions into the critic's input tile (the actor's output gate, then the critic's action-input gate)
+// (the gate mode is read from the kernel arguments inside the gated branch only: nothing of it is live in ungated runs)
 template <class NA, class NQ>
-__device__ __forceinline__ void actions_to_critic(const UpdView<NA, NQ> &V, bool target) {
+__device__ __forceinline__ void actions_to_critic(const DdpgParams &P, const UpdView<NA, NQ> &V, int agent, int u, bool target) {
   const LdsMap &M = V.M;
   for (int e = V.tid; e < DDRL_MB * V.A; e += DDRL_NTHREADS) {
     const int row = e / V.A, col = e - row * V.A;
     float a = M.topa[row * V.lda + col];
     if (V.agate) {
-      a *= ddrl_gate_factor(V.agate[col], V.gm.ac_bern, V.gm.ac_scale, V.gm.seed, V.draw, V.agent, target ? GS_ACTOR_T_OUT : GS_ACTOR_OUT, row, col);
+      const GateMode &gm = P.gm;
+      const unsigned draw = gm.draw + (unsigned)u;
+      a *= ddrl_gate_factor(V.agate[col], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, target ? GS_ACTOR_T_OUT : GS_ACTOR_OUT, row, col);
       M.topa[row * V.lda + col] = a;
-      a *= ddrl_gate_factor(V.agate[col], V.gm.ac_bern, V.gm.ac_scale, V.gm.seed, V.draw, V.agent, target ? GS_CRITIC_T_A : GS_CRITIC_A, row, col);
+      a *= ddrl_gate_factor(V.agate[col], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, target ? GS_CRITIC_T_A : GS_CRITIC_A, row, col);
     }
     M.xc[row * V.ldxc + V.S + col] = a;
   }
@@ -96,15 +97,15 @@ __device__ __forceinline__ void ddpg_q0(const DdpgParams &P, float *lds, int age
   // n-step horizon (DeepQNAg.hpp:360-373, 394-402): stops before a transition that reached the goal and at the end
   // of the replay; rewards of steps [0, valid) are discounted
   if (P.nstep > 0) nstep_horizon(P, S, A, agent, V.idx, B, len, head, gamma, M, tid);
-  gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, true, M, tid, V.draw);
+  gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, true, M, tid, u);
   ddrl_sync();
   fwd_net(na, na.L(), V.w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane, cy, true, fwd_first(nq, V.w_qt));
-  actions_to_critic(V, true);
+  actions_to_critic(P, V, agent, u, true);
   STAMP(1);
   fwd_net(nq, nq.L(), V.w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane, cy, true, fwd_first(nq, V.w_q));
   STAMP(2);
   // ---- TD targets (DeepQNAg.hpp:386-405) ----
-  gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, false, M, tid, V.draw);
+  gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, false, M, tid, u);
   int trow;
   if (gather_owns_row(tid, trow)) {     // the thread that gathered the row's reward / goal flag
     const float qn = M.topq[trow * ldq];
@@ -154,7 +155,7 @@ __device__ __forceinline__ void ddpg_q2(const DdpgParams &P, float *lds, int age
   const LdsMap &M = V.M;
   const int S = V.S, A = V.A, B = V.B, ldxc = V.ldxc, ldxa = V.ldxa, ldq = V.ldq, lda = V.lda, lane = V.lane, wave = V.wave;
   fwd_net(na, na.L(), V.w_a, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);       // pi = ann(s)
-  actions_to_critic(V, false);
+  actions_to_critic(P, V, agent, u, false);
   STAMP(6);
   fwd_net(nq, nq.L(), V.w_q, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);       // Q(s, pi(s)), new critic
   STAMP(7);
@@ -164,15 +165,19 @@ __device__ __forceinline__ void ddpg_q2(const DdpgParams &P, float *lds, int age
     // critic_backward (:429): only d/d(actions) is needed; critic parameter diffs are discarded
     float *topa = M.topa;
     const float *agate = V.agate;
-    const GateMode gm = V.gm;
-    const unsigned draw = V.draw;
+    const DdpgParams *Pg = &P;                                             // the gate mode: read only under a gate
     const int inverting = P.inverting, out_act = na.out_act();
     float *dact_out = P.dact_out && V.diag ? P.dact_out + (size_t)agent * B * A : nullptr;
     auto store = [=](int row, int h, float diff) {
       float out = topa[row * lda + h];
       // the masks of the forward passes these gradients belong to, regenerated from their keys
-      const float gin = agate ? ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_CRITIC_A, row, h) : 1.f;
-      const float gt = agate ? ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_ACTOR_OUT, row, h) : 1.f;
+      float gin = 1.f, gt = 1.f;
+      if (agate) {
+        const GateMode &gm = Pg->gm;
+        const unsigned draw = gm.draw + (unsigned)u;
+        gin = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_CRITIC_A, row, h);
+        gt = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_ACTOR_OUT, row, h);
+      }
       diff *= gin;                                                       // the critic's action-input gate
       if (inverting) {                                                   // :432-450
         if (diff < 0.f) diff *= (1.0f - out) / 2.0f;

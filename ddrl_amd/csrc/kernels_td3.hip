@@ -144,7 +144,14 @@ td3_update_kernel(const DdpgParams P) {
   // ---- qnn->learn_batch(s, a, y, 1); qnn2->learn_batch(s, a, y, 1) (:329-330; MLP.hpp:468-485) ----
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const float *wk = k == 0 ? w_q : w_q2;
+    int ag1 = agent, z1 = 0, tid1 = tid;                   // (laundered per pass: see the actor phase below)
+    asm volatile("" : "+s"(ag1), "+s"(z1));
+    asm volatile("" : "+v"(tid1));
+    const int agent = ag1, tid = tid1, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LdsMap M = ddpg_carve(lds + z1, na.L(), nq.L(), P.ldh, ldxc, ldxa, ldq, lda);
+    float *park = ParkOf<NA, NQ>::value ? M.topq : nullptr;
+    const float *wk = (k == 0 ? P.sq.w : P.sq2.w) + (size_t)agent * nq.stride();
     fwd_net(nq, nq.L(), wk, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
     if (tid < DDRL_MB) {
       // EuclideanLoss: loss = sum (q - y)^2 / (2B), dq = (q - y) / B
@@ -160,7 +167,19 @@ td3_update_kernel(const DdpgParams P) {
   }
 
   // ---- delayed actor update through the first critic (:333-363) ----
+  // Every value the actor phase shares with the critic phases (agent index, LDS base, thread id) is re-derived from a
+  // laundered copy: with the common subexpressions visible the compiler kept the actor phase's addresses and fragments
+  // alive across both critic passes and spilled ~110 vector registers (kernels_ddpg_pair.hip has the same cure).
+  int ag2 = agent, z2 = 0, tid2 = tid;
+  asm volatile("" : "+s"(ag2), "+s"(z2));
+  asm volatile("" : "+v"(tid2));
   if (actor_step) {                                        // uniform over the workgroup
+    const int agent = ag2, tid = tid2, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LdsMap M = ddpg_carve(lds + z2, na.L(), nq.L(), P.ldh, ldxc, ldxa, ldq, lda);
+    const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
+    const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_q = P.sq.w + (size_t)agent * nq.stride();
+    float *park = ParkOf<NA, NQ>::value ? M.topq : nullptr;
     fwd_net(na, na.L(), w_a, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);       // pi = ann(s)
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, col = e - row * A;

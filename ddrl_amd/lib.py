@@ -222,7 +222,7 @@ def load():
     partial = b"+f64" in L.ddrl_version()    # the fp64 debug build (csrc/pop_internal.h): the one-tile DDPG path only,
     REAL = np.float64 if partial else np.float32   # and the ABI's float arrays are double arrays
     for name, res, args in SYMBOLS:
-        if partial and not hasattr(L, name):
+        if (partial or os.environ.get("DDRL_POP_SO")) and not hasattr(L, name):    # (dev experiments: an older build)
             continue
         fn = getattr(L, name)     # AttributeError if the library does not export it
         fn.restype = res
