@@ -5,7 +5,7 @@
 // moving_average_fraction 0.999) and ScaleLayer.  Every tower works IN PLACE on the blob the preceding activation wrote,
 // so that activation's backward sees the tower's output (Caffe's in-place semantics, restated as is).
 //
-// A tower couples the rows of the minibatch: its passes are column-parallel (two threads per channel, 32 rows each) and
+// A tower couples the rows of the minibatch: its passes are column-parallel (2 to 16 threads per channel) and
 // sit between workgroup barriers, unlike the row-parallel InnerProduct passes.  Only rows < B take part; rows >= B are
 // kept at zero so that they stay out of the dW products.
 #pragma once
@@ -22,6 +22,18 @@ enum { BN_TRAIN = 0,       // batch statistics, running sums updated (a TRAIN-ph
 // (TEST-phase evaluation without a backward pass).
 struct BnBufs { float *x0, *h, *top, *den; };
 
+// threads per channel of a column pass: the largest power of two (2..16) that keeps every channel of the tower in one sweep of
+// the workgroup; a channel's threads are consecutive lanes of one wave, each walks every tpc-th row
+__device__ __forceinline__ int bn_threads_per_channel(int C) {
+  int tpc = 16;
+  while (tpc > 2 && C * tpc > DDRL_NTHREADS) tpc >>= 1;
+  return tpc;
+}
+__device__ __forceinline__ float bn_group_sum(float v, int tpc) {
+  for (int o = 1; o < tpc; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 // tower r over buf [64 x ld] (columns [0, C)), between barriers supplied by the caller
 __device__ __forceinline__ void bn_forward_cols(const NetDesc &nd, float *__restrict__ wblk, int r, int mode, int B,
                                                 float *buf, int ld, float *xn, float *den, int tid) {
@@ -31,31 +43,31 @@ __device__ __forceinline__ void bn_forward_cols(const NetDesc &nd, float *__rest
   const float *bet = nd.bn_bias() ? Pm + 3 * C4 + 4 : nullptr;
   const float factor = Pm[2 * C4];                       // read by every thread before thread 0 replaces it (barrier below)
   const float sf = factor == 0.f ? 0.f : 1.0f / factor;
-  const int half = tid & 1, r0 = half * (DDRL_MB / 2);
+  const int tpc = bn_threads_per_channel(C), sub = tid & (tpc - 1);
   const float invB = 1.0f / (float)B;
-  for (int c = tid >> 1; c < C; c += DDRL_NTHREADS / 2) {
+  for (int c = tid / tpc; c < C; c += DDRL_NTHREADS / tpc) {
     float mean, var;
     if (mode == BN_TEST) {
       mean = sf * Pm[c]; var = sf * Pm[C4 + c];
     } else {
       float s = 0.f;
-      for (int i = r0; i < r0 + DDRL_MB / 2; ++i) s += i < B ? buf[i * ld + c] : 0.f;
-      s += __shfl_xor(s, 1);
+      for (int i = sub; i < DDRL_MB; i += tpc) s += i < B ? buf[i * ld + c] : 0.f;
+      s = bn_group_sum(s, tpc);
       mean = s * invB;
       float q = 0.f;
-      for (int i = r0; i < r0 + DDRL_MB / 2; ++i) { const float xc = buf[i * ld + c] - mean; q += i < B ? xc * xc : 0.f; }
-      q += __shfl_xor(q, 1);
+      for (int i = sub; i < DDRL_MB; i += tpc) { const float xc = buf[i * ld + c] - mean; q += i < B ? xc * xc : 0.f; }
+      q = bn_group_sum(q, tpc);
       var = q * invB;
-      if (mode == BN_TRAIN && half == 0) {
+      if (mode == BN_TRAIN && sub == 0) {
         const float bc = B > 1 ? (float)B / (float)(B - 1) : 1.f;
         Pm[c] = mean + DDRL_BN_MAF * Pm[c];
         Pm[C4 + c] = bc * var + DDRL_BN_MAF * Pm[C4 + c];
       }
     }
     const float dn = sqrtf(var + DDRL_BN_EPS);
-    if (den && half == 0) den[r * DDRL_MAXW + c] = dn;
+    if (den && sub == 0) den[r * DDRL_MAXW + c] = dn;
     const float g = gam ? gam[c] : 1.f, b = bet ? bet[c] : 0.f;
-    for (int i = r0; i < r0 + DDRL_MB / 2; ++i) {
+    for (int i = sub; i < DDRL_MB; i += tpc) {
       const float x = i < B ? (buf[i * ld + c] - mean) / dn : 0.f;
       if (xn) xn[i * ld + c] = x;
       buf[i * ld + c] = i < B ? (gam ? fmaf(x, g, b) : x) : 0.f;
@@ -78,23 +90,23 @@ __device__ __forceinline__ void bn_backward_cols(const NetDesc &nd, const float 
   const float *Pm = wblk + nd.bn_off(r);
   const float *gam = nd.bn_scale() ? Pm + 2 * C4 + 4 : nullptr;
   const float *bet = nd.bn_bias() ? Pm + 3 * C4 + 4 : nullptr;
-  const int half = tid & 1, r0 = half * (DDRL_MB / 2);
+  const int tpc = bn_threads_per_channel(chi - clo), sub = tid & (tpc - 1);
   const float invB = 1.0f / (float)B;
-  for (int c = clo + (tid >> 1); c < chi; c += DDRL_NTHREADS / 2) {
+  for (int c = clo + tid / tpc; c < chi; c += DDRL_NTHREADS / tpc) {
     float s1 = 0.f, s2 = 0.f;
-    for (int i = r0; i < r0 + DDRL_MB / 2; ++i) {
+    for (int i = sub; i < DDRL_MB; i += tpc) {
       const float di = i < B ? d[i * ld + c] : 0.f;
       s1 += di; s2 += di * xn[i * ld + c];
     }
-    s1 += __shfl_xor(s1, 1);
-    s2 += __shfl_xor(s2, 1);
+    s1 = bn_group_sum(s1, tpc);
+    s2 = bn_group_sum(s2, tpc);
     const float g = gam ? gam[c] : 1.f, b = bet ? bet[c] : 0.f;
-    if (gout && half == 0) {
+    if (gout && sub == 0) {
       if (gam) gout[nd.bn_off(r) + 2 * C4 + 4 + c] = s2;
       if (bet) gout[nd.bn_off(r) + 3 * C4 + 4 + c] = s1;
     }
     const float m1 = g * s1 * invB, m2 = g * s2 * invB, dn = den[r * DDRL_MAXW + c];
-    for (int i = r0; i < r0 + DDRL_MB / 2; ++i) {
+    for (int i = sub; i < DDRL_MB; i += tpc) {
       const float x = xn[i * ld + c];
       float v = g * d[i * ld + c];
       v = test ? v / dn : (v - m1 - m2 * x) / dn;

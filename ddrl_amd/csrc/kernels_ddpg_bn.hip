@@ -22,7 +22,7 @@ struct BnLds {
 
 static __host__ __device__ size_t bn_lds_floats(const DdpgParams &P) {
   const int nh = (P.a.L_ > P.q.L_ ? P.a.L_ : P.q.L_) - 1;
-  const int ldq = P.q.ld_[P.q.L_], lda = P.a.ld_[P.a.L_];
+  const int ldq = P.q.ld_top(), lda = P.a.ld_top();
   size_t f = 2 * (size_t)nh * DDRL_MB * P.ldh;                        // hidden tiles + their x_norm copies
   f += 2 * (size_t)DDRL_MB * (P.ldxc + P.ldxa) + DDRL_NWAVES * 64;   // input tiles + copies, dump
   f += (size_t)DDRL_MB * (ldq + 3 * lda + 5);                         // topq, topa, its x_norm copy, pa, per-row scalars
@@ -76,7 +76,7 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
   if (!live || len < 250 || len < P.B) return;             // DeepQNAg.hpp:338
   const NetDesc &na = P.a, &nq = P.q;
-  const int S = P.S, A = P.A, B = P.B, ldxc = P.ldxc, ldxa = P.ldxa, ldq = nq.ld(nq.L()), lda = na.ld(na.L());
+  const int S = P.S, A = P.A, B = P.B, ldxc = P.ldxc, ldxa = P.ldxa, ldq = nq.ld_top(), lda = na.ld_top();
   const BnLds Z = bn_carve(lds, P, ldq, lda);
   const LdsMap &M = Z.M;
   const int *idx = P.idx + (size_t)agent * B;

@@ -133,9 +133,27 @@ struct NetDesc {
   __host__ __device__ bool bn_any() const { return bn_mask_ != 0; }
   __host__ __device__ bool bn_scale() const { return (bn_flags_ & 2) != 0; }
   __host__ __device__ bool bn_bias() const { return (bn_flags_ & 1) != 0; }
-  __host__ __device__ int bn_c(int r) const { return bn_c_[r]; }
-  __host__ __device__ int bn_c4(int r) const { return ddrl_roundup(bn_c_[r], 4); }
-  __host__ __device__ int bn_off(int r) const { return bn_off_[r]; }
+  // (select chains over constant indices: a run-time index into a by-value kernel argument makes the compiler copy the
+  // whole argument block to scratch)
+  __host__ __device__ int bn_c(int r) const {
+    int v = bn_c_[0];
+#pragma unroll
+    for (int i = 1; i <= DDRL_MAXL; ++i) v = r == i ? bn_c_[i] : v;
+    return v;
+  }
+  __host__ __device__ int ld_top() const {               // ld(L()) without a run-time index
+    int v = ld_[1];
+#pragma unroll
+    for (int i = 2; i <= DDRL_MAXL; ++i) v = L_ == i ? ld_[i] : v;
+    return v;
+  }
+  __host__ __device__ int bn_c4(int r) const { return ddrl_roundup(bn_c(r), 4); }
+  __host__ __device__ int bn_off(int r) const {
+    int v = bn_off_[0];
+#pragma unroll
+    for (int i = 1; i <= DDRL_MAXL; ++i) v = r == i ? bn_off_[i] : v;
+    return v;
+  }
   __host__ __device__ int bn_stats_floats(int r) const { return 2 * bn_c4(r) + 4; }
   __host__ __device__ int bn_floats(int r) const { return 4 * bn_c4(r) + 4; }
   __host__ __device__ int L() const { return L_; }
