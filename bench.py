@@ -468,7 +468,7 @@ def main():
                    "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": ("ddpg_update_pair_kernel" if upl >= 4 and PAIR_MODE else "ddpg_update_kernel") if max(ha + hq) <= 128 else "wide_* layer kernels, optimiser inside the dW kernels (one update = 45 launches)",
+                     "kernel": ("ddpg_update_pair_kernel" if (PAIR_MODE == 2 or (upl >= 4 and PAIR_MODE and args.size == "mid" and G > 512)) else "ddpg_update_kernel") if max(ha + hq) <= 128 else "wide_* layer kernels, optimiser inside the dW kernels (one update = 45 launches)",
                      "kernel_avg_ms": kavg * 1e3, "launches": launches,
                      "updates_per_launch": upl_eff, "algorithmic_bytes_per_launch": byts * G * upl_eff,
                      "algorithmic_bytes_per_agent_update": byts,

@@ -16,6 +16,7 @@ STUB_ERR(net_forward_bn_launch)
 STUB_ERR(net_forward_launch)
 STUB_ERR(net_forward_wide_launch)
 STUB_ZERO(ddpg_update_pair_ok)
+STUB_ZERO(ddpg_update_pair_pays)
 STUB_ZERO(ddpg_update_resident_ok)
 STUB_ZERO(ddpg_update_bn_lds_bytes)
 STUB_ZERO(ddpg_wide_block_floats)

@@ -27,6 +27,7 @@ hipError_t mt_seed_launch(uint32_t *mt, int *pos, const uint32_t *seeds, int G, 
 hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap, int rowlen, int S, int A,
                                 const float *s, const float *a, const float *r, const float *s2,
                                 const uint8_t *goal, const uint8_t *mask, hipStream_t st);
+int ddpg_update_pair_pays(const DdpgParams *P);
 hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st);
 size_t ddpg_update_bn_lds_bytes(const DdpgParams *P);
 hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G, hipStream_t st);
@@ -682,8 +683,8 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   h->P.sq = h->net[1].st;
   h->P.nupd = per_launch;
   // launches of several updates: two agents per workgroup, one quarter of an update apart (kernels_ddpg_pair.hip)
-  const bool pair = fused && !h->force_generic && h->pair_mode > 0 && (per_launch >= DDRL_PAIR_MIN_UPD || h->pair_mode == 2) &&
-                    ddpg_update_pair_ok(&h->P);
+  const bool pair = fused && !h->force_generic && h->pair_mode > 0 &&
+                    (h->pair_mode == 2 || (per_launch >= DDRL_PAIR_MIN_UPD && ddpg_update_pair_pays(&h->P))) && ddpg_update_pair_ok(&h->P);
   // small nets: the agent's whole state in LDS for the launch (worth the copy in / out from two updates on)
   // (opt-in, "resident" option: measured SLOWER than the one-agent kernel -- one workgroup per CU instead of three,
   // and the small nets' update is bound by its chain of tiny dependent passes, not by HBM: DESIGN.md section 4.1e)
