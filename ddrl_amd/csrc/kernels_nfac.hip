@@ -140,12 +140,83 @@ nfac_scan_kernel(const NfacParams P) {
   }
 }
 
+// Sum of the chunk partials in chunk order, then updateFisher(nsample) / regularize() /
+// ApplyUpdate() / set_iter(iter + 1) (MLP.hpp:479-482; OfflineCaclaAg.hpp:567-570) on 4 parameters
+// per thread and step.  iter_add: Adam steps already applied during this update (iter itself is bumped once
+// at the end by nfac_finish_kernel).  One agent: elements [i0, i0 + 4 * 256 * nsweep) of its block, 256 threads.
+template <int MODE, bool EWC>
+__device__ __forceinline__ void nfac_apply_agent(const NfacParams &P, int agent, int iter_add, int last, int i0, int nsweep, bool bookkeeping,
+                                                 int tid, float *s_lrt) {
+  const int T = P.len[agent];
+  const int npos = MODE == 1 ? P.n_pos[agent] : 1;
+  const NetDesc &nd = MODE == 0 ? P.v : P.a;
+  const NetState &st = MODE == 0 ? P.sv : P.sa;
+  const int nch = (T + DDRL_MB - 1) / DDRL_MB;
+  if (tid == 0) {
+    const int t = st.iter[agent] + iter_add + 1;
+    const double corr = sqrt(1.0 - pow(P.dbeta2, (double)t)) / (1.0 - pow(P.dbeta1, (double)t));
+    *s_lrt = (float)((double)st.lr[agent] * corr);
+  }
+  __syncthreads();
+  const float nsample = MODE == 0 ? (float)T : (float)npos;
+  OptCtx o;
+  o.dump = nullptr;
+  const size_t off = (size_t)agent * nd.stride();
+  o.w = st.w + off; o.m = st.m + off; o.v = st.v + off; o.wt = nullptr;
+  o.fisher = EWC ? st.fisher + off : nullptr;
+  o.fhat = EWC ? st.fhat + off : nullptr;
+  o.wstar = EWC ? st.wstar + off : nullptr;
+  o.lr_t = *s_lrt; o.tau = 0.f; o.omtau = 0.f;
+  o.decay = -1.f;                                  // OfflineCaclaAg.hpp:186,190: no weight decay
+  o.ewc_coef = EWC ? st.ewc_coef[agent] : 0.f;
+  o.fisher_beta = P.fisher_beta; o.nsample = nsample;
+  o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
+  o.handoff = 0;
+  for (int sw = 0; sw < nsweep; ++sw) {
+    const int i = i0 + (sw * 256 + tid) * 4;
+    if (i < nd.stride()) {
+      OptRegs r;
+      opt_load4<EWC, false, false>(o, i, r);
+      const float *gp = (MODE == 0 ? P.gpart_v : P.gpart_a) + (size_t)agent * P.maxchunks * nd.stride() + i;
+      f32x4 g = *(const f32x4 *)gp;
+      for (int c = 1; c < nch; ++c) g += *(const f32x4 *)(gp + (size_t)c * nd.stride());
+      opt_step4<EWC, false, false>(o, i, g, r, true);
+    }
+  }
+  if (bookkeeping && tid == 0) {
+    if (EWC) st.fisher_nbr[agent] = st.fisher_nbr[agent] * P.fisher_beta + nsample;   // DODevMLP.hpp:655
+    if (MODE == 0 && last) {
+      float s = 0.f;
+      for (int c = 0; c < nch; ++c) s += P.loss_part[(size_t)agent * P.maxchunks + c];
+      P.loss_out[agent] = s / (float)T * 0.5f;
+    }
+  }
+}
+
+template <int MODE, bool EWC>
+__global__ void __launch_bounds__(256)
+nfac_apply_kernel(const NfacParams P, int iter_add, int last) {
+  const int agent = blockIdx.y, tid = threadIdx.x;
+  if (P.mask && !P.mask[agent]) return;
+  if (P.len[agent] <= 0) return;
+  if (MODE == 1 && P.n_pos[agent] <= 0) return;
+  __shared__ float s_lrt;
+  nfac_apply_agent<MODE, EWC>(P, agent, iter_add, last, blockIdx.x * 1024, 1, blockIdx.x == 0, tid, &s_lrt);
+}
+
 // One chunk of one full-batch gradient.  MODE 0: critic, EuclideanLoss against tgt (MLP.hpp:950-957:
 // d yhat = (yhat - y) / T).  MODE 1: actor, top diff = -(target - pi(s)) on the selected rows with
 // optional inverting gradient (OfflineCaclaAg.hpp:531-566), no 1/T.
-template <int MODE, class ND>
+// P.fuse: the step itself rides in this launch -- every chunk workgroup publishes its partial (sc1 stores, the wave's vmcnt(0),
+// barrier, one relaxed agent-scope counter increment: the hand-off forms of kernels_ddpg.hip), and the workgroup that
+// finds the agent's other chunks done takes an agent-scope acquire and runs nfac_apply_agent over the agent's block while
+// other agents' chunks are still computing.  Same reduction order and arithmetic as nfac_apply_kernel: bit-identical
+// (tests/test_nfac_gpu.py).  Measured on config 3 (256 agents): 20.9 ms per update against 15.2 ms with the separate apply
+// launches -- the write-through stores of 59 MB of partials per launch hold every chunk workgroup at its vmcnt(0), and the
+// one workgroup that steps an agent walks 14 streams with nothing else in flight -- so it is opt-in (option "nfac_fuse").
+template <int MODE, class ND, bool EWC>
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU (<= 256 registers)
-nfac_grad_kernel(const NfacParams P) {
+nfac_grad_kernel(const NfacParams P, int iter_add, int last) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -171,7 +242,7 @@ nfac_grad_kernel(const NfacParams P) {
       const float df = li < T ? M.top[tid * ldt] - P.tgt[ro + li] : 0.f;
       float sq = df * df;
       for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-      if (tid == 0) P.loss_part[(size_t)agent * P.maxchunks + chunk] = sq;
+      if (tid == 0) store_sc1(P.loss_part + (size_t)agent * P.maxchunks + chunk, sq);
       M.top[tid * ldt] = df / (float)T;
     }
   } else {
@@ -199,64 +270,28 @@ nfac_grad_kernel(const NfacParams P) {
   __syncthreads();
   auto none = [](int, int, float) {};
   OptCtx unused = {};
+  unused.handoff = P.fuse;                            // partials read by another workgroup of this launch: sc1 stores
   float *gout = (MODE == 0 ? P.gpart_v : P.gpart_a) + ((size_t)agent * P.maxchunks + chunk) * nd.stride();
   bwd_net<DW_STORE, false>(nd, w, unused, gout, M.x, ldx, M.hbase, M.hstride, M.top, ldt, 0, 0, none, wave, lane, tid);
-}
-
-// Sum of the chunk partials in chunk order, then updateFisher(nsample) / regularize() /
-// ApplyUpdate() / set_iter(iter + 1) (MLP.hpp:479-482; OfflineCaclaAg.hpp:567-570) on 4 parameters
-// per thread.  iter_add: Adam steps already applied during this update (iter itself is bumped once
-// at the end by nfac_finish_kernel).
-template <int MODE, bool EWC>
-__global__ void __launch_bounds__(256)
-nfac_apply_kernel(const NfacParams P, int iter_add, int last) {
-  const int agent = blockIdx.y, tid = threadIdx.x;
-  if (P.mask && !P.mask[agent]) return;
-  const int T = P.len[agent];
-  if (T <= 0) return;
-  const int npos = MODE == 1 ? P.n_pos[agent] : 1;
-  if (npos <= 0) return;
-  const NetDesc &nd = MODE == 0 ? P.v : P.a;
-  const NetState &st = MODE == 0 ? P.sv : P.sa;
-  const int nch = (T + DDRL_MB - 1) / DDRL_MB;
+  if (!P.fuse) return;                                // uniform
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int s_last;
   __shared__ float s_lrt;
   if (tid == 0) {
-    const int t = st.iter[agent] + iter_add + 1;
-    const double corr = sqrt(1.0 - pow(P.dbeta2, (double)t)) / (1.0 - pow(P.dbeta1, (double)t));
-    s_lrt = (float)((double)st.lr[agent] * corr);
+    const int nch = (T + DDRL_MB - 1) / DDRL_MB;
+    const int before = __hip_atomic_fetch_add(P.chunk_done + agent, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int mine = before == nch - 1;
+    if (mine) {
+      __hip_atomic_store(P.chunk_done + agent, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = mine;
   }
   __syncthreads();
-  const float nsample = MODE == 0 ? (float)T : (float)npos;
-  OptCtx o;
-  o.dump = nullptr;
-  const size_t off = (size_t)agent * nd.stride();
-  o.w = st.w + off; o.m = st.m + off; o.v = st.v + off; o.wt = nullptr;
-  o.fisher = EWC ? st.fisher + off : nullptr;
-  o.fhat = EWC ? st.fhat + off : nullptr;
-  o.wstar = EWC ? st.wstar + off : nullptr;
-  o.lr_t = s_lrt; o.tau = 0.f; o.omtau = 0.f;
-  o.decay = -1.f;                                  // OfflineCaclaAg.hpp:186,190: no weight decay
-  o.ewc_coef = EWC ? st.ewc_coef[agent] : 0.f;
-  o.fisher_beta = P.fisher_beta; o.nsample = nsample;
-  o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
-  o.handoff = 0;
-  const int i = (blockIdx.x * 256 + tid) * 4;
-  if (i < nd.stride()) {
-    OptRegs r;
-    opt_load4<EWC, false, false>(o, i, r);
-    const float *gp = (MODE == 0 ? P.gpart_v : P.gpart_a) + (size_t)agent * P.maxchunks * nd.stride() + i;
-    f32x4 g = *(const f32x4 *)gp;
-    for (int c = 1; c < nch; ++c) g += *(const f32x4 *)(gp + (size_t)c * nd.stride());
-    opt_step4<EWC, false, false>(o, i, g, r, true);
-  }
-  if (blockIdx.x == 0 && tid == 0) {
-    if (EWC) st.fisher_nbr[agent] = st.fisher_nbr[agent] * P.fisher_beta + nsample;   // DODevMLP.hpp:655
-    if (MODE == 0 && last) {
-      float s = 0.f;
-      for (int c = 0; c < nch; ++c) s += P.loss_part[(size_t)agent * P.maxchunks + c];
-      P.loss_out[agent] = s / (float)T * 0.5f;
-    }
-  }
+  if (!s_last) return;
+  nfac_apply_agent<MODE, EWC>(P, agent, iter_add, last, 0, (nd.stride() + 1023) / 1024, true, tid, &s_lrt);
 }
 
 // vnn_from_scratch (OfflineCaclaAg.hpp:281-284): the critic of every agent with a trajectory is replaced by the freshly
@@ -317,22 +352,27 @@ extern "C" hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen
   return hipGetLastError();
 }
 
-template <int MODE, class ND>
-static hipError_t grad_launch_t(const NfacParams *P, int chunks, size_t lds, hipStream_t st) {
+template <int MODE, class ND, bool EWC>
+static hipError_t grad_launch_t(const NfacParams *P, int chunks, size_t lds, int iter_add, int last, hipStream_t st) {
   static LdsConfig conf;
-  hipError_t e = ddrl_set_lds(nfac_grad_kernel<MODE, ND>, lds, conf);
+  hipError_t e = ddrl_set_lds(nfac_grad_kernel<MODE, ND, EWC>, lds, conf);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((nfac_grad_kernel<MODE, ND>), dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  hipLaunchKernelGGL((nfac_grad_kernel<MODE, ND, EWC>), dim3(chunks, P->G), dim3(DDRL_NTHREADS), lds, st, *P, iter_add, last);
   return hipGetLastError();
 }
-extern "C" hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, hipStream_t st) {
+template <int MODE, class ND>
+static hipError_t grad_launch_e(const NfacParams *P, int chunks, size_t lds, int iter_add, int last, hipStream_t st) {
+  const bool ewc = P->fuse && (MODE == 0 ? P->sv : P->sa).fisher != nullptr;     // (unfused: the template flag is unused)
+  return ewc ? grad_launch_t<MODE, ND, true>(P, chunks, lds, iter_add, last, st) : grad_launch_t<MODE, ND, false>(P, chunks, lds, iter_add, last, st);
+}
+extern "C" hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, int iter_add, int last, hipStream_t st) {
   const size_t lds = nfac_lds_bytes(mode == 0 ? P->v : P->a, P->ldh);
   if (mode == 0) {
-    if (!P->generic && Cfg3Critic::matches(P->v)) return grad_launch_t<0, Cfg3Critic>(P, chunks, lds, st);
-    return grad_launch_t<0, NetDesc>(P, chunks, lds, st);
+    if (!P->generic && Cfg3Critic::matches(P->v)) return grad_launch_e<0, Cfg3Critic>(P, chunks, lds, iter_add, last, st);
+    return grad_launch_e<0, NetDesc>(P, chunks, lds, iter_add, last, st);
   }
-  if (!P->generic && Cfg3Actor::matches(P->a)) return grad_launch_t<1, Cfg3Actor>(P, chunks, lds, st);
-  return grad_launch_t<1, NetDesc>(P, chunks, lds, st);
+  if (!P->generic && Cfg3Actor::matches(P->a)) return grad_launch_e<1, Cfg3Actor>(P, chunks, lds, iter_add, last, st);
+  return grad_launch_e<1, NetDesc>(P, chunks, lds, iter_add, last, st);
 }
 
 extern "C" hipError_t nfac_apply_launch(const NfacParams *P, int mode, int iter_add, int last, hipStream_t st) {

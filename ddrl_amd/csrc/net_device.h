@@ -8,7 +8,7 @@
 __device__ __forceinline__ void bwd_dw_store(const float *__restrict__ dYs, int ldy, int N,
                                              const float *__restrict__ Xs, int ldx, int kp,
                                              int offw, int offb, float *__restrict__ gout,
-                                             int wave, int lane, int tid) {
+                                             int wave, int lane, int tid, bool sc1 = false) {   // sc1: read by another workgroup of this launch
   const int g = lane >> 4, c = lane & 15;
   const int NT = (N + 15) >> 4, KT = (kp + 15) >> 4;
   const int total = NT * KT;
@@ -16,9 +16,12 @@ __device__ __forceinline__ void bwd_dw_store(const float *__restrict__ dYs, int 
     bool ok;
     const int i = dw_elem(p, total, KT, N, kp, offw, c, g, ok);
     const f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p, total, KT, c, g);
-    if (ok) *(f32x4 *)(gout + i) = acc;
+    if (ok) { if (sc1) store_sc1(gout + i, acc); else *(f32x4 *)(gout + i) = acc; }
   }
-  for (int n = tid; n < N; n += DDRL_NTHREADS) gout[offb + n] = bias_grad(dYs, ldy, n);
+  for (int n = tid; n < N; n += DDRL_NTHREADS) {
+    const float bg = bias_grad(dYs, ldy, n);
+    if (sc1) store_sc1(gout + offb + n, bg); else gout[offb + n] = bg;
+  }
 }
 
 // a wave's LDS stores must have landed before the same wave's later loads of other lanes' values
@@ -140,7 +143,7 @@ __device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w
             if (kt0 + i < kt1) acc[i] = *(const f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4);
         }
       }
-      else bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid);
+      else bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid, opt.handoff != 0);
       if (bst && tid == 0 && ll < 2) bst[2 * ll + 1] = clock64();
       ddrl_sync();   // every wave has read H_{l-1} before its rows are overwritten by dZ_{l-1}
     }

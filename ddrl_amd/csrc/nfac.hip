@@ -10,7 +10,7 @@ extern "C" {
 size_t nfac_lds_need(const NfacParams *P);
 hipError_t nfac_values_launch(const NfacParams *P, int chunks, hipStream_t st);
 hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen, hipStream_t st);
-hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, hipStream_t st);
+hipError_t nfac_grad_launch(const NfacParams *P, int mode, int chunks, int iter_add, int last, hipStream_t st);
 hipError_t nfac_apply_launch(const NfacParams *P, int mode, int iter_add, int last, hipStream_t st);
 hipError_t nfac_finish_launch(const NfacParams *P, int critic_steps, int actor_steps, hipStream_t st);
 hipError_t nfac_reinit_launch(const NfacParams *P, const float *fresh, hipStream_t st);
@@ -29,6 +29,7 @@ struct NfacHost {
         *d_loss_part = nullptr, *d_loss = nullptr, *d_pa = nullptr;
   uint8_t *d_rowmode = nullptr;
   int *d_npos = nullptr;
+  int *d_chunk_done = nullptr;                // [G] nfac_grad_kernel's per-agent count of published chunk partials (self-resetting)
   float *d_fresh = nullptr;                   // vnn_from_scratch: the freshly drawn critics of one fitted iteration [G x stride]
   std::mt19937_64 scratch_eng;                // ... and the engine they come from
 };
@@ -174,6 +175,7 @@ extern "C" int ddrl_nfac_create(const ddrl_nfac_config *cfg, uint64_t init_seed,
   if ((rc = dalloc(h, &n->d_deltas, (size_t)G * maxT))) return bail(rc);
   if ((rc = dalloc(h, &n->d_rowmode, (size_t)G * maxT))) return bail(rc);
   if ((rc = dalloc(h, &n->d_npos, G))) return bail(rc);
+  if ((rc = dalloc(h, &n->d_chunk_done, G))) return bail(rc);
   // zeroed once: the kernels never write the pad elements, so they stay 0
   if ((rc = dalloc(h, &n->d_gpart_a, (size_t)G * n->maxchunks * h->net[0].nd.stride()))) return bail(rc);
   if ((rc = dalloc(h, &n->d_gpart_v, (size_t)G * n->maxchunks * h->net[1].nd.stride()))) return bail(rc);
@@ -233,6 +235,7 @@ extern "C" int ddrl_nfac_create(const ddrl_nfac_config *cfg, uint64_t init_seed,
   P.dbeta1 = b1; P.dbeta2 = b2;
   P.traj = n->d_traj; P.len = n->d_len; P.endflag = n->d_endflag; P.gamma = h->d_gamma;
   P.V = n->d_V; P.nextV = n->d_nextV; P.tgt = n->d_tgt; P.deltas = n->d_deltas; P.rowmode = n->d_rowmode;
+  P.chunk_done = n->d_chunk_done;
   P.n_pos = n->d_npos; P.gpart_a = n->d_gpart_a; P.gpart_v = n->d_gpart_v; P.loss_part = n->d_loss_part; P.loss_out = n->d_loss;
   if (nfac_lds_need(&P) > 160 * 1024) return bail(ddrl_fail(DDRL_EINVAL, "network too wide for the LDS-resident kernels (%zu bytes of LDS)", nfac_lds_need(&P)));
   if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(ddrl_fail(DDRL_EHIP, "sync failed"));
@@ -337,10 +340,10 @@ static int launch_critic(ddrl_pop *h, NfacHost *n, int chunks, int maxlen, int &
       hipEvent_t pe;                                   // profiling on: the critic's gradient launches are the ones timed
       int prc = prof_begin(h, &pe);
       if (prc) return prc;
-      HIPCHK(nfac_grad_launch(&n->P, 0, chunks, h->stream));
-      if ((prc = prof_end(h, pe))) return prc;
       const int last = fit == c.number_fitted_iteration - 1 && it == c.stoch_iter_critic - 1;
-      HIPCHK(nfac_apply_launch(&n->P, 0, steps, last, h->stream));
+      HIPCHK(nfac_grad_launch(&n->P, 0, chunks, steps, last, h->stream));
+      if ((prc = prof_end(h, pe))) return prc;
+      if (!n->P.fuse) HIPCHK(nfac_apply_launch(&n->P, 0, steps, last, h->stream));
       ++steps;
     }
   }
@@ -373,6 +376,7 @@ extern "C" int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask) {
   HIPCHK(hipMemcpyAsync(n->d_len, n->h_len.data(), G * sizeof(int), hipMemcpyHostToDevice, h->stream));
   n->P.mask = dmask;
   n->P.generic = h->force_generic ? 1 : 0;
+  n->P.fuse = h->nfac_fuse ? 1 : 0;
   n->P.sgate = h->gates_on ? h->d_sgate : nullptr;
   n->P.agate = h->gates_on ? h->d_agate : nullptr;
   n->P.sa = h->net[0].st;
@@ -386,8 +390,8 @@ extern "C" int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask) {
     HIPCHK(nfac_scan_launch(&n->P, 1, maxlen, h->stream));                                              // :464-522
     for (int sia = 0; sia < c.stoch_iter_actor; ++sia) {                                                // :527-572
       n->P.gm = next_draw(h, 1);
-      HIPCHK(nfac_grad_launch(&n->P, 1, chunks, h->stream));
-      HIPCHK(nfac_apply_launch(&n->P, 1, sia, 0, h->stream));
+      HIPCHK(nfac_grad_launch(&n->P, 1, chunks, sia, 0, h->stream));
+      if (!n->P.fuse) HIPCHK(nfac_apply_launch(&n->P, 1, sia, 0, h->stream));
     }
     if (!c.update_critic_first && (rc = launch_critic(h, n, chunks, maxlen, critic_steps))) return rc;  // :585-587
     HIPCHK(nfac_finish_launch(&n->P, critic_steps, c.stoch_iter_actor, h->stream));

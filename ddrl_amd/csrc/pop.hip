@@ -1175,6 +1175,7 @@ extern "C" int ddrl_pop_debug_stamps(ddrl_pop_t *h, int enable, long long *out) 
 extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
   if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (std::string(key) == "force_generic") { h->force_generic = value != 0; return DDRL_OK; }
+  if (std::string(key) == "nfac_fuse") { h->nfac_fuse = value != 0; return DDRL_OK; }
   if (std::string(key) == "resident") { h->resident_mode = value != 0; return DDRL_OK; }
   if (std::string(key) == "pair") { h->pair_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "force_chunked") {     // the gradient + apply kernels of the large-minibatch path on one-tile minibatches

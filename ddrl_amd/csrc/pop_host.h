@@ -81,6 +81,7 @@ struct ddrl_pop {
   int force_generic = 0;
   bool multi_pending = false;   // a multi-update launch was issued since the error word was last read (ddrl_pop_wait)
   int resident_mode = 0;      // 1: small nets keep an agent's whole state in LDS for a multi-update launch (ddpg_update_resident_kernel)
+  int nfac_fuse = 0;          // NFAC, option "nfac_fuse": 1 = the optimiser step inside the gradient launch (bit-identical; measured SLOWER, kernels_nfac.hip), 0 = separate nfac_apply_kernel launches
   int pair_mode = 1;          // 0: never the two-agents-per-workgroup kernel, 1: for launches of >= DDRL_PAIR_MIN_UPD updates, 2: whenever it fits
   bool force_chunked = false;
   bool wide = false;               // some layer is wider than DDRL_MAXW: layer-by-layer update kernels

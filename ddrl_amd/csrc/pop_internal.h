@@ -265,6 +265,8 @@ struct NfacParams {
   float corr_factor;
   int value_passes;               // nfac_values_kernel: bit 0 = V(s), bit 1 = V(s')
   int generic;                    // 1: never the compile-time-shape instantiations (option "force_generic")
+  int fuse;                       // 1: the last chunk workgroup of an agent reduces the partials and steps (nfac_grad_kernel); 0: nfac_apply_kernel
+  int *chunk_done;                // [G] chunk workgroups of the running gradient launch that have published their partials
   float lambda;
   float beta1, beta2, omb1, omb2, eps, fisher_beta;
   double dbeta1, dbeta2;

@@ -348,3 +348,30 @@ def test_from_scratch_refused_with_critic_ewc():
     cfg = ddrl_amd.NfacConfig(n_agents=1, nb_sensors=4, nb_motors=1, vnn_from_scratch=1, ewc=10.0, ewc_for_critic=1)
     with pytest.raises(DdrlError, match="vnn_from_scratch"):
         ddrl_amd.NfacPopulation(cfg, init_seed=1)
+
+
+@pytest.mark.parametrize("shape", ["config3", "other"])
+def test_step_inside_the_gradient_launch_is_bit_identical(ora, shape):
+    """option nfac_fuse = 1: the last chunk workgroup of an agent reduces the partials and steps inside the gradient
+    launch; 0 (default: faster): a separate nfac_apply_kernel launch per step.  Same reduction order and arithmetic: identical bits, for the
+    compile-time-shape kernels (config 3's nets) and the run-time-shape ones, with EWC live and ragged trajectories."""
+    S, A = (45, 17) if shape == "config3" else (18, 6)
+    ha = hv = (64, 64) if shape == "config3" else (32, 16)
+    G, maxT = 5, 512
+    res = []
+    for fuse in (1, 0):
+        pop, agents, _ = make_pair(ora, G, S, A, ha, hv, maxT, seed=12, lambda_=0.9, gae=1, ewc=10.0, ewc_for_critic=1,
+                                   number_fitted_iteration=3, stoch_iter_critic=4, stoch_iter_actor=3)
+        pop.set_option("nfac_fuse", fuse)
+        rng = np.random.RandomState(4)
+        for upd in range(3):
+            load_trajs(pop, rng, [500, 64, 65, 1, 333], S, A)
+            pop.update(mask=np.array([1, 1, 1, 1, 0], np.uint8) if upd == 1 else None)
+            if upd == 0:
+                pop.update_best_param(np.ones(G)); pop.ewc_setup()
+        last = pop.last()
+        res.append([pop.weights(0), pop.weights(1)] + list(pop.adam(0)) + list(pop.adam(1)) + [last["deltas"], last["critic_loss"], last["n_pos"]]
+                   + [pop.ewc_state(n)["fisher"] for n in (0, 1)])
+        pop.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
