@@ -493,3 +493,47 @@ def test_fused_consecutive_updates_full_chip(pair):
     for k in la:
         assert np.array_equal(la[k], lb[k]), k
     assert np.all(a.adam(1)[2] == 1 + 2 * n)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4])
+def test_best_param_methods_pick_the_reference_snapshot(ora, method):
+    """DODevMLP::update_best_param_previous_task (DODevMLP.hpp:722-758): which weights become the anchor of the next ewc_setup.
+    0 / 4: the best score so far; 1: the latest; 2: the best score, or anything once the snapshot is more than 50 calls old;
+    3: the first call after a setup.  The device snapshot is a copy: the anchor must equal the chosen weights bit for bit,
+    per agent (agents see different score sequences)."""
+    G = 2
+    pop, _ = make_pair(ora, G=G, hidden_a=(16,), hidden_q=(16,), ewc=10.0, ewc_fisher_beta=0.99, ewc_for_critic=1,
+                       ewc_best_method=method, wscale=0.1, seed=method)
+    rng = np.random.RandomState(method)
+    n_calls = 60 if method == 2 else 6
+    scores = np.stack([np.r_[5.0, rng.uniform(0, 4, n_calls - 1)], np.r_[1.0, 2.0, 3.0, rng.uniform(0, 2.5, n_calls - 3)]], 1)   # [call][agent]
+    snaps = []
+    best = [-np.inf] * G; age = [0] * G; chosen = [None] * G
+    for k in range(n_calls):
+        pop.update()
+        snaps.append([pop.weights(0), pop.weights(1)])
+        pop.update_best_param(scores[k])
+        for g in range(G):
+            s = scores[k, g]
+            if method in (0, 4):
+                go = s > best[g]
+            elif method == 1:
+                go = True
+            elif method == 2:
+                too_old = age[g] > 50
+                age[g] += 1
+                go = s > best[g] or too_old
+                if go:
+                    age[g] = 0
+            else:
+                age[g] += 1
+                go = age[g] == 1
+            if go:
+                best[g] = s; chosen[g] = k
+    pop.ewc_setup()
+    for net in (0, 1):
+        ws = pop.ewc_state(net)["wstar"]
+        for g in range(G):
+            assert np.array_equal(ws[g], snaps[chosen[g]][net][g]), (method, net, g, chosen[g])
+    if method == 2:
+        assert chosen[0] > 0          # agent 0's first score is never beaten: only the age rule can have replaced its snapshot
