@@ -369,7 +369,7 @@ struct OptRegs { f32x4 w, m, v, wt, fisher, fhat, wstar; };
 // EWC: the net has Fisher / anchor arrays (DODevMLP.hpp:604-707).  TGT: the net has a target twin
 // that is soft-updated in the same pass (MLP.hpp:437-452).
 template <bool EWC, bool TGT, bool NT = true>
-__device__ __forceinline__ void opt_load4(const OptCtx o, int i, OptRegs &r) {
+__device__ __forceinline__ void opt_load4(const OptCtx &o, int i, OptRegs &r) {
 #ifdef DDRL_EXP_NOOPTMEM
   r.w = r.m = r.v = r.wt = r.fisher = r.fhat = r.wstar = (f32x4){(float)i, 1.f, 2.f, 3.f};
   return;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void opt_load4(const OptCtx o, int i, OptRegs &r) {
 // <= 0 = off), Adam (caffe AdamSolver::ComputeUpdateValue + Net::Update) and the target net's soft
 // update (MLP.hpp:449-450): one read and one write of each array per update, no branches.
 template <bool EWC, bool TGT, bool NT = true>
-__device__ __forceinline__ void opt_step4(const OptCtx o, int i, f32x4 grad, const OptRegs &r, bool ok) {
+__device__ __forceinline__ void opt_step4(const OptCtx &o, int i, f32x4 grad, const OptRegs &r, bool ok) {
   f32x4 w = r.w, m, v, f, wt;
   if (EWC) {
     f = r.fisher * o.fisher_beta + (grad * grad) * o.nsample;
@@ -424,7 +424,7 @@ __device__ __forceinline__ void opt_step4(const OptCtx o, int i, f32x4 grad, con
 
 // scalar form (biases)
 template <bool EWC, bool TGT>
-__device__ __forceinline__ void opt_step(const OptCtx o, int i, float grad) {
+__device__ __forceinline__ void opt_step(const OptCtx &o, int i, float grad) {
   float w = o.w[i];
   if (EWC) {
     o.fisher[i] = o.fisher[i] * o.fisher_beta + (grad * grad) * o.nsample;
@@ -443,13 +443,13 @@ __device__ __forceinline__ void opt_step(const OptCtx o, int i, float grad) {
 // the same step with the state already in registers (requested at the start of the phase)
 struct OptRegs1 { float w, m, v, wt, fisher, fhat, wstar; };
 template <bool EWC, bool TGT>
-__device__ __forceinline__ void opt_load1(const OptCtx o, int i, OptRegs1 &r) {
+__device__ __forceinline__ void opt_load1(const OptCtx &o, int i, OptRegs1 &r) {
   r.w = o.w[i]; r.m = o.m[i]; r.v = o.v[i];
   if (TGT) r.wt = o.wt[i];
   if (EWC) { r.fisher = o.fisher[i]; r.fhat = o.fhat[i]; r.wstar = o.wstar[i]; }
 }
 template <bool EWC, bool TGT>
-__device__ __forceinline__ void opt_step1(const OptCtx o, int i, float grad, const OptRegs1 &r, bool ok) {
+__device__ __forceinline__ void opt_step1(const OptCtx &o, int i, float grad, const OptRegs1 &r, bool ok) {
   float w = r.w, f = 0.f;
   if (EWC) {
     f = r.fisher * o.fisher_beta + (grad * grad) * o.nsample;
@@ -531,7 +531,7 @@ __device__ __forceinline__ float bias_grad(const float *__restrict__ dYs, int ld
 template <bool EWC, bool TGT, bool SETS3 = false>
 __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ldy, int N,
                                            const float *__restrict__ Xs, int ldx, int kp,
-                                           int offw, int offb, const OptCtx o,
+                                           int offw, int offb, const OptCtx &o,
                                            int wave, int lane, int tid) {
   const int g = lane >> 4, c = lane & 15;
   const int NT = (N + 15) >> 4, KT = (kp + 15) >> 4;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 struct FwdCarry { BFrag b0, b1; };
 
 template <class ND>
-__device__ __forceinline__ FwdNext fwd_first(const ND nd, const float *__restrict__ w) {
+__device__ __forceinline__ FwdNext fwd_first(const ND &nd, const float *__restrict__ w) {
   FwdNext nx = {w + nd.offw(0), w + nd.offb(0), nd.kp(0), nd.d(1)};
   return nx;
 }
@@ -51,7 +51,7 @@ __device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry
 }
 
 template <class ND>
-__device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__restrict__ w,
+__device__ __forceinline__ void fwd_net(const ND &nd, int nl, const float *__restrict__ w,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                         int wave, int lane, FwdCarry &cy, bool preloaded, const FwdNext after) {
   const float *in = X;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__rest
 
 // a pass on its own: nothing requested ahead, nothing handed over
 template <class ND>
-__device__ __forceinline__ void fwd_net(const ND nd, int nl, const float *__restrict__ w,
+__device__ __forceinline__ void fwd_net(const ND &nd, int nl, const float *__restrict__ w,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                         int wave, int lane) {
   FwdCarry cy;
@@ -102,7 +102,7 @@ enum { DW_NONE = 0, DW_OPT = 1, DW_STORE = 2 };
 #define DDRL_PARK_TILES 4     // input-gradient tiles (of up to DDRL_MAXKC) parked in LDS during a deep layer's optimiser loop
 // TGT: the optimiser epilogue also moves the net's target twin (false: TD3's critics between two policy steps)
 template <int TRAIN, bool EWC, bool TGT = true, class ND, class DX0>
-__device__ __forceinline__ void bwd_net(const ND nd, const float *__restrict__ w, const OptCtx opt, float *gout,
+__device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ w, const OptCtx &opt, float *gout,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                         int c0, int nc, DX0 dx0_store, int wave, int lane, int tid,
                                         long long *bst = nullptr,     // bst: diagnostic s_memtime slots (dX done / dW done per layer)

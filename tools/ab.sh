@@ -1,0 +1,23 @@
+set -e
+mkdir -p gpurun_out/r02/ab
+run() { # name, env, args
+  local name=$1; shift; local so=$1; shift
+  if [ -n "$so" ]; then DDRL_POP_SO=$PWD/tools/bin/libbase.so timeout -k 10 200 python bench.py --no-cpu "$@" > gpurun_out/r02/ab/$name.json 2>/dev/null
+  else timeout -k 10 200 python bench.py --no-cpu "$@" > gpurun_out/r02/ab/$name.json 2>/dev/null; fi
+}
+run new_def "" 
+run base_def base
+run new_def2 ""
+run base_def2 base
+run new_128 "" --agents 128
+run base_128 base --agents 128
+run new_p0 "" --pair 0
+run base_p0 base --pair 0
+run new_large "" --size large --steps 20 --warmup 4
+run base_large base --size large --steps 20 --warmup 4
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r02/ab/*.json")):
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split("/")[-1], round(d["value"]), round(d["ms_per_step"], 4), d["roofline"].get("kernel_avg_ms"))
+PY
