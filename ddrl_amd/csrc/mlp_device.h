@@ -389,19 +389,32 @@ __device__ __forceinline__ void opt_load4(const OptCtx &o, int i, OptRegs &r) {
 // fhat / wstar are all-zero until the first ewc_setup), L2 decay (caffe SGDSolver::Regularize; decay
 // <= 0 = off), Adam (caffe AdamSolver::ComputeUpdateValue + Net::Update) and the target net's soft
 // update (MLP.hpp:449-450): one read and one write of each array per update, no branches.
+// A per-agent scalar of the optimiser context, as the wave-uniform value it is.  Besides keeping it in a scalar register,
+// this stands between the context's field and the vector expression it scales: a scalar load that feeds a vector splat
+// directly is widened by the compiler into a 16-byte load spanning the neighbouring fields, after which the context can
+// no longer be split into registers and lives in scratch memory (seen in wide_dw_kernel: 11 stores + 8 loads per workgroup).
+__device__ __forceinline__ float uni(float x) {
+#ifdef DDRL_F64_DEBUG
+  return x;
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+#endif
+}
+
 template <bool EWC, bool TGT, bool NT = true>
 __device__ __forceinline__ void opt_step4(const OptCtx &o, int i, f32x4 grad, const OptRegs &r, bool ok) {
   f32x4 w = r.w, m, v, f, wt;
   if (EWC) {
-    f = r.fisher * o.fisher_beta + (grad * grad) * o.nsample;
-    grad += o.ewc_coef * r.fhat * (w - r.wstar);
+    f = r.fisher * uni(o.fisher_beta) + (grad * grad) * uni(o.nsample);
+    grad += uni(o.ewc_coef) * r.fhat * (w - r.wstar);
   }
-  grad += fmaxf(o.decay, 0.f) * w;
-  m = o.omb1 * grad + o.beta1 * r.m;
-  v = o.omb2 * (grad * grad) + o.beta2 * r.v;
+  grad += fmaxf(uni(o.decay), 0.f) * w;
+  m = uni(o.omb1) * grad + uni(o.beta1) * r.m;
+  v = uni(o.omb2) * (grad * grad) + uni(o.beta2) * r.v;
+  const float lr_t = uni(o.lr_t), eps = uni(o.eps);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) w[e] -= o.lr_t * (m[e] * adam_rdenom(v[e], o.eps));
-  if (TGT) wt = o.tau * w + o.omtau * r.wt;
+  for (int e = 0; e < 4; ++e) w[e] -= lr_t * (m[e] * adam_rdenom(v[e], eps));
+  if (TGT) wt = uni(o.tau) * w + uni(o.omtau) * r.wt;
 #ifdef DDRL_EXP_NOOPTMEM
   ok = ok && (w[0] + wt[1] + m[2] + v[3] + (EWC ? f[0] : 0.f) == 12345.678f);
 #endif

@@ -1,20 +1,21 @@
+# same-box A/B: the tree's library against tools/bin/libbase.so (a build of another commit), bench lines side by side
 set -e
 mkdir -p gpurun_out/r02/ab
-run() { # name, env, args
+run() { # name, "base" or "", bench arguments
   local name=$1; shift; local so=$1; shift
   if [ -n "$so" ]; then DDRL_POP_SO=$PWD/tools/bin/libbase.so timeout -k 10 200 python bench.py --no-cpu "$@" > gpurun_out/r02/ab/$name.json 2>/dev/null
   else timeout -k 10 200 python bench.py --no-cpu "$@" > gpurun_out/r02/ab/$name.json 2>/dev/null; fi
 }
-run new_def "" 
+run new_def ""
 run base_def base
 run new_def2 ""
 run base_def2 base
 run new_128 "" --agents 128
 run base_128 base --agents 128
-run new_p0 "" --pair 0
-run base_p0 base --pair 0
-run new_large "" --size large --steps 20 --warmup 4
-run base_large base --size large --steps 20 --warmup 4
+run new_large "" --size large --steps 30 --warmup 4
+run base_large base --size large --steps 30 --warmup 4
+run new_nfac "" --workload nfac
+run base_nfac base --workload nfac
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r02/ab/*.json")):
