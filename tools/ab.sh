@@ -12,8 +12,8 @@ run new_def2 ""
 run base_def2 base
 run new_128 "" --agents 128
 run base_128 base --agents 128
-run new_large "" --size large --steps 30 --warmup 4
-run base_large base --size large --steps 30 --warmup 4
+run new_small "" --size small
+run base_small base --size small
 run new_nfac "" --workload nfac
 run base_nfac base --workload nfac
 python - <<PY
