@@ -1,0 +1,26 @@
+"""No kernel of the product library uses scratch memory or spills vector registers.
+
+Round 2 found stack objects in the update kernels that the source did not show (an optimiser context passed by value; a
+scalar field load widened into a vector load over its neighbours): DESIGN.md section 4.1.  The code-object metadata of the
+built library is the place where that shows, so it is held here.  CPU test: reads the library's .hip_fatbin with the
+ROCm LLVM tools, runs nothing on a GPU.
+"""
+import os, sys
+import pytest
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(HERE, "tools"))
+import kernel_meta as km
+
+SO = os.path.join(HERE, "ddrl_amd", "libddrl_pop.so")
+
+
+@pytest.mark.skipif(not km.tools_present() or not os.path.exists(SO), reason="ROCm LLVM tools or the built library are absent")
+def test_no_kernel_uses_scratch_or_spills_vector_registers():
+    meta = km.kernel_meta(SO)
+    assert len(meta) >= 60, "expected the library's kernels, found %d" % len(meta)
+    for want in ("ddpg_update_kernel", "ddpg_update_pair_kernel", "td3_update_kernel", "nfac_grad_kernel", "wide_dw_kernel",
+                 "ddpg_update_bn_kernel", "ddpg_chunk_kernel"):
+        assert any(want in k for k in meta), want
+    bad = {k: m for k, m in meta.items() if m.get("scratch", 0) != 0 or m.get("vgpr_spill", 0) != 0}
+    assert not bad, "kernels with scratch memory / spilled vector registers: %r" % bad
