@@ -79,6 +79,74 @@ __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, i
   }
 }
 
+// The same gather in two halves, for the kernels with compile-time shapes: gather_load only REQUESTS the thread's
+// share of its row (idx[row], then NCOL row elements + reward / goal flag: two dependent memory round trips, 2-5 k
+// cycles each under load) into registers; gather_store applies the gates and writes the LDS tiles.  The request can
+// therefore be issued a whole pass -- or a whole quarter of an update -- before the tiles are needed: the replay ring
+// and the index block are constant during a launch (the prep kernel drew the indices of all its updates), so nothing
+// orders it behind the previous update's stores.  nstep_return > 0 keeps gather_tile (the row depends on the
+// horizon computed in LDS).
+#define DDRL_GATHER_MAXC 8
+struct GatherRegs { float v[DDRL_GATHER_MAXC]; float r, dn; };
+
+template <int NCOL>
+__device__ __forceinline__ void gather_load(const DdpgParams &P, int S, int A, int ldxc, int agent,
+                                            const int *__restrict__ idx, int B, int head, bool next, int tid, GatherRegs &g) {
+  constexpr int TPR = DDRL_GATHER_TPR;
+  static_assert(NCOL <= DDRL_GATHER_MAXC, "gather_load: more columns per thread than GatherRegs holds");
+  const float *rep = P.rep + (size_t)agent * P.cap * P.rowlen;
+  const int row = tid / TPR, q = tid - row * TPR;
+  const bool live = row < B;
+  int phys = 0;
+  if (live) {
+    phys = head + idx[row];
+    if (phys >= P.cap) phys -= P.cap;
+  }
+  const float *rr = rep + (size_t)phys * P.rowlen;
+#pragma unroll
+  for (int j = 0; j < NCOL; ++j) {
+    const int col = q + j * TPR;
+    float v = 0.f;
+    if (live && col < ldxc) {
+      if (next) { if (col < S) v = rr[S + A + col]; }
+      else if (col < S + A) v = rr[col];
+    }
+    g.v[j] = v;
+  }
+  g.r = 0.f; g.dn = 0.f;
+  if (!next && q == 0 && live) { g.r = rr[2 * S + A]; g.dn = rr[2 * S + A + 1]; }
+}
+
+template <int NCOL>
+__device__ __forceinline__ void gather_store(const DdpgParams &P, int S, int A, int ldxc, int ldxa, int agent, int B, bool next,
+                                             const LdsMap &M, int tid, int u, const GatherRegs &g) {
+  constexpr int TPR = DDRL_GATHER_TPR;
+  const int row = tid / TPR, q = tid - row * TPR;
+  const bool live = row < B;
+  const float *sg = P.sgate ? P.sgate + (size_t)agent * S : nullptr, *ag = P.agate ? P.agate + (size_t)agent * A : nullptr;
+#pragma unroll
+  for (int j = 0; j < NCOL; ++j) {
+    const int col = q + j * TPR;
+    if (col < ldxc) {
+      const float v = g.v[j];
+      float vc = v, va = v;
+      if (live && (sg || ag)) {          // the gates of gather_tile
+        const GateMode &gm = P.gm;
+        const unsigned draw = gm.draw + (unsigned)u;
+        if (sg && col < S) {
+          vc *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_CRITIC_T_S : GS_CRITIC_S, row, col);
+          va *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_ACTOR_T_S : GS_ACTOR_S, row, col);
+        }
+        if (ag && col >= S && col < S + A)
+          vc *= ddrl_gate_factor(ag[col - S], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_CRITIC_A_REPLAY, row, col - S);
+      }
+      M.xc[row * ldxc + col] = vc;
+      if (col < ldxa) M.xa[row * ldxa + col] = col < S ? va : 0.f;
+    }
+  }
+  if (!next && q == 0) { M.rv[row] = g.r; M.dn[row] = g.dn; }
+}
+
 template <bool EWC>
 __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &s, int stride,
                                            int agent, float tau, float omtau, float nsample, int u = 0) {
@@ -96,6 +164,11 @@ __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &
   o.fisher_beta = P.fisher_beta;
   o.nsample = nsample;
   o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
+#ifdef DDRL_EXP_NOMSKIP
+  o.mld = o.m;
+#else
+  o.mld = P.beta1 == 0.f ? o.w : o.m;
+#endif
   o.dump = nullptr;
   o.handoff = P.nupd > 1 && !P.pair;     // the pair kernel keeps an agent's consecutive updates in one workgroup
   return o;

@@ -77,8 +77,29 @@ __device__ __forceinline__ void actions_to_critic(const DdpgParams &P, const Upd
 }
 
 // ---- q0: a' = ann_target(s'), q' = qnn_target(s', a') (DeepQNAg.hpp:379-383), TD targets (:386-405), critic forward + loss seed (:408) ----
+// columns of the critic's input tile per gathering thread (compile-time shapes)
+template <class NQ> struct GatherCols { static constexpr int value = (NQ::ld(0) + DDRL_GATHER_TPR - 1) / DDRL_GATHER_TPR; };
+template <> struct GatherCols<NetDesc> { static constexpr int value = 1; };
+// can this instantiation split its gathers into request / commit halves (ddpg_device.h)?
+template <class NA, class NQ> struct GatherSplit {
+  static constexpr bool value = !__is_same(NA, NetDesc) && !__is_same(NQ, NetDesc) && GatherCols<NQ>::value <= DDRL_GATHER_MAXC;
+};
+
+// the s' rows of update u of this launch, requested ahead of the update (before the hand-off wait of kernels_ddpg.hip,
+// during the previous update's last quarter in kernels_ddpg_pair.hip); false: not this instantiation / configuration
+template <class NA, class NQ>
+__device__ __forceinline__ bool ddpg_prefetch_rows(const DdpgParams &P, int agent, int u, int head, int tid, GatherRegs &g) {
+  if (!GatherSplit<NA, NQ>::value || P.nstep > 0 || u >= P.nupd) return false;
+  const auto &na = Pick<NA>::get(P.a);
+  const auto &nq = Pick<NQ>::get(P.q);
+  gather_load<GatherCols<NQ>::value>(P, na.d(0), na.d(na.L()), nq.ld(0), agent, P.idx + ((size_t)agent * P.nupd + u) * P.B, P.B, head, true, tid, g);
+  return true;
+}
+
+// pre / have_pre: the s' rows already requested by ddpg_prefetch_rows
 template <class NA, class NQ, bool EWC_A, bool EWC_Q>
-__device__ __forceinline__ void ddpg_q0(const DdpgParams &P, float *lds, int agent, int u, int len, int head, float gamma, int tid) {
+__device__ __forceinline__ void ddpg_q0(const DdpgParams &P, float *lds, int agent, int u, int len, int head, float gamma, int tid,
+                                        const GatherRegs &pre, bool have_pre) {
   const auto &na = Pick<NA>::get(P.a);
   const auto &nq = Pick<NQ>::get(P.q);
   const UpdView<NA, NQ> V = upd_view<NA, NQ>(P, lds, agent, u, tid);
@@ -96,8 +117,19 @@ __device__ __forceinline__ void ddpg_q0(const DdpgParams &P, float *lds, int age
 #endif
   // n-step horizon (DeepQNAg.hpp:360-373, 394-402): stops before a transition that reached the goal and at the end
   // of the replay; rewards of steps [0, valid) are discounted
-  if (P.nstep > 0) nstep_horizon(P, S, A, agent, V.idx, B, len, head, gamma, M, tid);
-  gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, true, M, tid, u);
+  // compile-time shapes, one-step targets: both gathers of the update are REQUESTED here (the second one's rows wait in
+  // registers through the two target passes); else the one-piece gathers
+  constexpr int NCOL = GatherCols<NQ>::value;
+  const bool split = GatherSplit<NA, NQ>::value && P.nstep <= 0;
+  GatherRegs g1, g2;
+  if (split) {
+    if (have_pre) g1 = pre; else gather_load<NCOL>(P, S, A, ldxc, agent, V.idx, B, head, true, tid, g1);
+    gather_load<NCOL>(P, S, A, ldxc, agent, V.idx, B, head, false, tid, g2);
+    gather_store<NCOL>(P, S, A, ldxc, ldxa, agent, B, true, M, tid, u, g1);
+  } else {
+    if (P.nstep > 0) nstep_horizon(P, S, A, agent, V.idx, B, len, head, gamma, M, tid);
+    gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, true, M, tid, u);
+  }
   ddrl_sync();
   fwd_net(na, na.L(), V.w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane, cy, true, fwd_first(nq, V.w_qt));
   actions_to_critic(P, V, agent, u, true);
@@ -105,7 +137,8 @@ __device__ __forceinline__ void ddpg_q0(const DdpgParams &P, float *lds, int age
   fwd_net(nq, nq.L(), V.w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane, cy, true, fwd_first(nq, V.w_q));
   STAMP(2);
   // ---- TD targets (DeepQNAg.hpp:386-405) ----
-  gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, false, M, tid, u);
+  if (split) gather_store<NCOL>(P, S, A, ldxc, ldxa, agent, B, false, M, tid, u, g2);
+  else gather_tile(P, S, A, ldxc, ldxa, agent, V.idx, B, head, false, M, tid, u);
   int trow;
   if (gather_owns_row(tid, trow)) {     // the thread that gathered the row's reward / goal flag
     const float qn = M.topq[trow * ldq];
@@ -116,7 +149,7 @@ __device__ __forceinline__ void ddpg_q0(const DdpgParams &P, float *lds, int age
   if (P.qt_out && V.diag && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];
   STAMP(3);
   // ---- critic update: qnn->learn_batch(s, a, y, 1)  (DeepQNAg.hpp:408; MLP.hpp:468-485) ----
-  fwd_net(nq, nq.L(), V.w_q, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane, cy, true, no_next);
+  fwd_net<NQ, false>(nq, nq.L(), V.w_q, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane, cy, true, no_next);
   if (tid < DDRL_MB) {
     // EuclideanLoss: loss = sum (q - y)^2 / (2B), dq = (q - y) / B
     const float df = tid < B ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
@@ -141,9 +174,48 @@ __device__ __forceinline__ void ddpg_q1(const DdpgParams &P, float *lds, int age
 #endif
   OptCtx oq = make_opt<EWC_Q>(P, P.sq, nq.stride(), agent, tau, omtau, (float)V.B, u);
   oq.dump = M.dump;
+#ifdef DDRL_EXP_PRIO
+  __builtin_amdgcn_s_setprio(2);
+#endif
   bwd_net<DW_OPT, EWC_Q>(nq, V.w_q, oq, nullptr, M.xc, V.ldxc, M.hbase, M.hstride, M.topq, V.ldq, 0, 0, none, V.wave, V.lane, tid,
                          V.stamps ? V.stamps + 11 : nullptr, V.park);
+#ifdef DDRL_EXP_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   STAMP(5);
+}
+
+// The actor's hidden activations share their LDS tiles with the critic passes that follow pi = ann(s).  Row-parallel
+// passes: a wave wrote rows 16w .. 16w+15 of every hidden tile itself, and those 16 rows are one contiguous run of
+// 16 ld floats.  Compile-time shapes keep them in REGISTERS across the two critic passes (mid nets: 13 float4 per lane)
+// and put them back before the actor's backward pass, instead of running the actor's hidden layers a second time
+// (252 of an update's 2 912 MFMAs per wave, one more read of the actor's weights, 25-30 k of its ~500 k cycles).
+// Exact: the second forward pass recomputed the same values from the same inputs.
+template <class NA> struct KeepHidden {
+  static constexpr int per(int l) { return (4 * NA::ld(l + 1) + 63) / 64; }          // float4 per lane of hidden tile l
+  static constexpr int before(int l) { int t = 0; for (int i = 0; i < l; ++i) t += per(i); return t; }
+  static constexpr int total = before(NA::L() - 1);
+  static constexpr bool value = total >= 1 && total <= 16;
+};
+template <> struct KeepHidden<NetDesc> { static constexpr int total = 1; static constexpr bool value = false; };
+
+template <class NA, bool SAVE>
+__device__ __forceinline__ void keep_hidden(float *hbase, int hstride, int wave, int lane, f32x4 (&keep)[KeepHidden<NA>::total]) {
+  if constexpr (KeepHidden<NA>::value) {
+#pragma unroll
+    for (int l = 0; l < NA::L() - 1; ++l) {
+      const int ld = NA::ld(l + 1), nf4 = 4 * ld;                  // float4s in this wave's 16 rows
+      float *base = hbase + l * hstride + 16 * wave * ld;
+#pragma unroll
+      for (int j = 0; j < KeepHidden<NA>::per(l); ++j) {
+        const int f = lane + 64 * j;
+        if (f < nf4) {
+          if (SAVE) keep[KeepHidden<NA>::before(l) + j] = *(const f32x4 *)(base + 4 * f);
+          else *(f32x4 *)(base + 4 * f) = keep[KeepHidden<NA>::before(l) + j];
+        }
+      }
+    }
+  }
 }
 
 // ---- q2: pi = ann(s), Q(s, pi(s)) with the NEW critic, dQ/da (DeepQNAg.hpp:411-455), the actor's hidden activations again ----
@@ -155,6 +227,8 @@ __device__ __forceinline__ void ddpg_q2(const DdpgParams &P, float *lds, int age
   const LdsMap &M = V.M;
   const int S = V.S, A = V.A, B = V.B, ldxc = V.ldxc, ldxa = V.ldxa, ldq = V.ldq, lda = V.lda, lane = V.lane, wave = V.wave;
   fwd_net(na, na.L(), V.w_a, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);       // pi = ann(s)
+  f32x4 keep[KeepHidden<NA>::total];
+  keep_hidden<NA, true>(M.hbase, M.hstride, wave, lane, keep);            // own rows: written by this wave, no barrier needed
   actions_to_critic(P, V, agent, u, false);
   STAMP(6);
   fwd_net(nq, nq.L(), V.w_q, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);       // Q(s, pi(s)), new critic
@@ -194,7 +268,15 @@ __device__ __forceinline__ void ddpg_q2(const DdpgParams &P, float *lds, int age
   STAMP(8);
   // the actor's hidden activations shared their LDS with the critic pass: recompute them (one extra
   // actor forward is cheaper than doubling LDS and halving occupancy); topa now holds dZ_L
-  fwd_net(na, na.L() - 1, V.w_a, M.xa, ldxa, M.hbase, M.hstride, nullptr, 0, wave, lane);
+  if constexpr (KeepHidden<NA>::value) {
+    // the critic's hidden tiles have the critic's row stride: another wave's rows of its passes may lie where this
+    // wave's actor rows go, so every wave must be through the input-gradient pass first
+    ddrl_sync();
+    keep_hidden<NA, false>(M.hbase, M.hstride, wave, lane, keep);
+    ddrl_sync();
+  } else {
+    fwd_net(na, na.L() - 1, V.w_a, M.xa, ldxa, M.hbase, M.hstride, nullptr, 0, wave, lane);
+  }
   STAMP(9);
 }
 
@@ -209,8 +291,14 @@ __device__ __forceinline__ void ddpg_q3(const DdpgParams &P, float *lds, int age
   {
     OptCtx oa = make_opt<EWC_A>(P, P.sa, na.stride(), agent, tau, omtau, (float)V.B, u);  // updateFisher(traj.size()) :456
     oa.dump = M.dump;
+#ifdef DDRL_EXP_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
     bwd_net<DW_OPT, EWC_A>(na, V.w_a, oa, nullptr, M.xa, V.ldxa, M.hbase, M.hstride, M.topa, V.lda, 0, 0, none, V.wave, V.lane, tid, nullptr, V.park);
   }
+#ifdef DDRL_EXP_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   STAMP(10);
   if (tid == 0) {
     if (handoff) {     // read by the agent's next update in this launch: sc1 stores (see store_sc1)

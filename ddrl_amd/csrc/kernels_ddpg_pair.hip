@@ -33,10 +33,20 @@ ddpg_update_pair_kernel(const DdpgParams P, int team_floats) {
   live = live && on && len >= 250 && len >= P.B;              // DeepQNAg.hpp:338
   float *tl = lds + (size_t)team * team_floats;
   const int nq = 4 * P.nupd;
+  // the s' rows of the NEXT update are requested at the end of an update's last quarter (and those of the first update
+  // here): they are in registers when its first quarter starts (ddpg_prefetch_rows)
+  GatherRegs pre;
+  bool have_pre = live && ddpg_prefetch_rows<NA, NQ>(P, ag, 0, head, tid, pre);
   __syncthreads();
 #pragma unroll 1
   for (int t = 0; t <= nq; ++t) {
+#if defined(DDRL_EXP_INPHASE)      // measurement: both teams of a workgroup in the same quarter; odd workgroups one quarter behind even ones
+    const int tt = t - ((int)blockIdx.x & 1);
+#elif defined(DDRL_EXP_INPHASE0)   // measurement: every team of the chip in the same quarter
+    const int tt = t;
+#else
     const int tt = t - team;                                  // team 1 runs one quarter behind team 0
+#endif
     if (live && tt >= 0 && tt < nq) {
       const int u = tt >> 2;
       // every quarter derives its addresses afresh from values the optimiser cannot see through: hoisted out of
@@ -46,10 +56,13 @@ ddpg_update_pair_kernel(const DdpgParams P, int team_floats) {
       asm volatile("" : "+v"(tid_it));
       float *tl_it = tl + z;
       switch (tt & 3) {
-        case 0: ddpg_q0<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, len, head, gamma, tid_it); break;
+        case 0: ddpg_q0<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, len, head, gamma, tid_it, pre, have_pre); break;
         case 1: ddpg_q1<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, tau, omtau, tid_it); break;
         case 2: ddpg_q2<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, tid_it); break;
-        default: ddpg_q3<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, tau, omtau, tid_it, false); break;
+        default:
+          ddpg_q3<NA, NQ, EWC_A, EWC_Q>(P, tl_it, a_it, u, tau, omtau, tid_it, false);
+          have_pre = ddpg_prefetch_rows<NA, NQ>(P, a_it, u + 1, head, tid_it, pre);
+          break;
       }
     }
     __syncthreads();                                          // both teams: the quarter boundary
@@ -106,7 +119,8 @@ ddpg_update_resident_kernel(const DdpgParams P, int act_floats) {
     asm volatile("" : "+s"(a_it), "+s"(z));
     asm volatile("" : "+v"(tid_it));
     float *tl = lds + z;
-    ddpg_q0<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, len, head, gamma, tid_it);
+    GatherRegs pre;
+    ddpg_q0<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, len, head, gamma, tid_it, pre, false);
     ddpg_q1<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, tau, omtau, tid_it);
     ddpg_q2<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, tid_it);
     ddpg_q3<NA, NQ, EWC_A, EWC_Q>(Q, tl, a_it, u, tau, omtau, tid_it, false);

@@ -171,6 +171,7 @@ __device__ __forceinline__ void nfac_apply_agent(const NfacParams &P, int agent,
   o.ewc_coef = EWC ? st.ewc_coef[agent] : 0.f;
   o.fisher_beta = P.fisher_beta; o.nsample = nsample;
   o.beta1 = P.beta1; o.beta2 = P.beta2; o.omb1 = P.omb1; o.omb2 = P.omb2; o.eps = P.eps;
+  o.mld = P.beta1 == 0.f ? o.w : o.m;
   o.handoff = 0;
   for (int sw = 0; sw < nsweep; ++sw) {
     const int i = i0 + (sw * 256 + tid) * 4;

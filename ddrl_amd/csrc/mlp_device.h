@@ -150,7 +150,11 @@ __device__ __forceinline__ void load_bfrag(const float *__restrict__ W, const fl
     if (kc * 16 < kp) {                       // uniform (folds for compile-time shapes)
       const int kw = ddrl_tile_kw(kc, kp);
       const float *blk = W + ddrl_tile_base(nt, kc, kp) + c * kw;
+#ifdef DDRL_EXP_WNT
+      b.v[kc] = __builtin_nontemporal_load((const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4)));
+#else
       b.v[kc] = *(const f32x4 *)(blk + (4 * g < kw ? 4 * g : kw - 4));   // k >= kp: finite filler, meets a zero A column
+#endif
     }
   }
 }
@@ -227,6 +231,31 @@ __device__ __forceinline__ void fwd_layer(const float *__restrict__ Xs, int ldx,
       for (int r = 0; r < 4; ++r) yrow[r * ldy + n] = n < N ? act_fwd(act, acc[r] + bv) : 0.f;
     }
   };
+#ifdef DDRL_FWD_SETS4
+  // Four weight-fragment sets in rotation: the loads for tile nt + 3 are issued before tile nt is computed.  Under load
+  // (a second team streaming its optimiser state through the same CU) a fragment load takes ~3.5 k cycles, two tiles of
+  // MFMAs (~1.8 k) did not cover it: the forward passes ran at the loads' pace.
+  {
+    BFrag b3;
+    if (2 < NT) load_bfrag(W, bias, kp, N, 2, lane, b2);
+    if (3 < NT) load_bfrag(W, bias, kp, N, 3, lane, b3);
+#pragma unroll 1
+    for (int nt = 0; nt < NT; nt += 4) {
+      const bool tail = nt + 4 >= NT;
+      store(nt, row_tile(a, b0, kp), b0.bias);
+      if (nt + 4 < NT) load_bfrag(W, bias, kp, N, nt + 4, lane, b0);
+      else if (tail && nW) load_bfrag(nW, nb, nx.kp, nx.N, 0, lane, b0);
+      if (nt + 1 < NT) store(nt + 1, row_tile(a, b1, kp), b1.bias);
+      if (nt + 5 < NT) load_bfrag(W, bias, kp, N, nt + 5, lane, b1);
+      else if (tail && nW && 1 < nNT) load_bfrag(nW, nb, nx.kp, nx.N, 1, lane, b1);
+      if (nt + 2 < NT) store(nt + 2, row_tile(a, b2, kp), b2.bias);
+      if (nt + 6 < NT) load_bfrag(W, bias, kp, N, nt + 6, lane, b2);
+      if (nt + 3 < NT) store(nt + 3, row_tile(a, b3, kp), b3.bias);
+      if (nt + 7 < NT) load_bfrag(W, bias, kp, N, nt + 7, lane, b3);
+    }
+    return;
+  }
+#endif
   // a real loop: fully unrolled, the scheduler hoists every tile's weight loads and spills
 #pragma unroll 1
   for (int nt = 0; nt < NT; nt += 3) {
@@ -263,7 +292,11 @@ __device__ __forceinline__ void load_wcol(const float *__restrict__ W, int kp, i
     if (nc * 16 < N) {
       const float *blk = W + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + cc;   // pad rows (n >= N) hold zeros
 #pragma unroll
+#ifdef DDRL_EXP_WNT
+      for (int j = 0; j < 4; ++j) b.v[nc][j] = __builtin_nontemporal_load(blk + j * kw);
+#else
       for (int j = 0; j < 4; ++j) b.v[nc][j] = blk[j * kw];
+#endif
     }
 }
 
@@ -288,6 +321,24 @@ __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, i
   W = opaque(W);
   AFrag a;
   load_afrag(dYs, ldy, ddrl_roundup(N, 4), wave, lane, a);
+#ifdef DDRL_DX_SETS3
+  {
+    // three weight-column sets: tile kt + 2 is requested before tile kt is computed (see fwd_layer)
+    WCol b[3];
+    if (kt0 < kt1) load_wcol(W, kp, N, kt0, lane, b[0]);
+    if (kt0 + 1 < kt1) load_wcol(W, kp, N, kt0 + 1, lane, b[1]);
+#pragma unroll
+    for (int i = 0; i < DDRL_MAXKC; ++i) {
+      const int kt = kt0 + i;
+      if (kt < kt1) {
+        if (kt + 2 < kt1) load_wcol(W, kp, N, kt + 2, lane, b[(i + 2) % 3]);
+        acc[i] = dx_tile(a, b[i % 3], N);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
+#endif
   WCol b0, b1;
   if (kt0 < kt1) load_wcol(W, kp, N, kt0, lane, b0);
 #pragma unroll
@@ -313,6 +364,11 @@ __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, i
 struct OptCtx {
   float *w, *m, *v, *wt, *fisher;
   const float *fhat, *wstar;
+  // where the first moment is LOADED from.  With beta1 == 0 (agent.momentum 0 / 2, MLP.hpp:160-173) the new moment is
+  // 1 * g + 0 * m: the old one is never needed, so the load is pointed at the weights' own lines (already on their way
+  // for this tile: served by the L1, no HBM traffic) and its finite value is multiplied by zero.  No branch, no second
+  // instantiation; 4 of the optimiser's 28 B/param of reads are gone.
+  const float *mld;
   float lr_t, tau, omtau, decay, ewc_coef, fisher_beta, nsample;
   float beta1, beta2, omb1, omb2, eps;
   float *dump;       // LDS dump area for l2_touch (null: none)
@@ -370,12 +426,12 @@ struct OptRegs { f32x4 w, m, v, wt, fisher, fhat, wstar; };
 // that is soft-updated in the same pass (MLP.hpp:437-452).
 template <bool EWC, bool TGT, bool NT = true>
 __device__ __forceinline__ void opt_load4(const OptCtx &o, int i, OptRegs &r) {
-#ifdef DDRL_EXP_NOOPTMEM
+#if defined(DDRL_EXP_NOOPTMEM) || defined(DDRL_EXP_NOOPTLD)
   r.w = r.m = r.v = r.wt = r.fisher = r.fhat = r.wstar = (f32x4){(float)i, 1.f, 2.f, 3.f};
   return;
 #endif
   r.w = *(const f32x4 *)(o.w + i);
-  r.m = stream_ld<NT>(o.m + i);
+  r.m = stream_ld<NT>(o.mld + i);
   r.v = stream_ld<NT>(o.v + i);
   if (TGT) r.wt = *(const f32x4 *)(o.wt + i);
   if (EWC) {
@@ -401,7 +457,7 @@ __device__ __forceinline__ float uni(float x) {
 #endif
 }
 
-template <bool EWC, bool TGT, bool NT = true>
+template <bool EWC, bool TGT, bool NT = true, bool PRED = true>     // PRED false: every lane stores (its index is a parameter's or the dump's)
 __device__ __forceinline__ void opt_step4(const OptCtx &o, int i, f32x4 grad, const OptRegs &r, bool ok) {
   f32x4 w = r.w, m, v, f, wt;
   if (EWC) {
@@ -415,10 +471,10 @@ __device__ __forceinline__ void opt_step4(const OptCtx &o, int i, f32x4 grad, co
 #pragma unroll
   for (int e = 0; e < 4; ++e) w[e] -= lr_t * (m[e] * adam_rdenom(v[e], eps));
   if (TGT) wt = uni(o.tau) * w + uni(o.omtau) * r.wt;
-#ifdef DDRL_EXP_NOOPTMEM
+#if defined(DDRL_EXP_NOOPTMEM) || defined(DDRL_EXP_NOOPTST)
   ok = ok && (w[0] + wt[1] + m[2] + v[3] + (EWC ? f[0] : 0.f) == 12345.678f);
 #endif
-  if (ok) {                                   // stores only: nothing waits on them
+  if (!PRED || ok) {                          // stores only: nothing waits on them
     if (o.handoff) {                          // uniform
       if (EWC) store_sc1(o.fisher + i, f);
       store_sc1(o.m + i, m);
@@ -444,7 +500,7 @@ __device__ __forceinline__ void opt_step(const OptCtx &o, int i, float grad) {
     grad += o.ewc_coef * o.fhat[i] * (w - o.wstar[i]);
   }
   grad += fmaxf(o.decay, 0.f) * w;
-  const float m = o.omb1 * grad + o.beta1 * o.m[i];
+  const float m = o.omb1 * grad + o.beta1 * o.mld[i];
   const float v = o.omb2 * (grad * grad) + o.beta2 * o.v[i];
   o.m[i] = m;
   o.v[i] = v;
@@ -457,7 +513,7 @@ __device__ __forceinline__ void opt_step(const OptCtx &o, int i, float grad) {
 struct OptRegs1 { float w, m, v, wt, fisher, fhat, wstar; };
 template <bool EWC, bool TGT>
 __device__ __forceinline__ void opt_load1(const OptCtx &o, int i, OptRegs1 &r) {
-  r.w = o.w[i]; r.m = o.m[i]; r.v = o.v[i];
+  r.w = o.w[i]; r.m = o.mld[i]; r.v = o.v[i];
   if (TGT) r.wt = o.wt[i];
   if (EWC) { r.fisher = o.fisher[i]; r.fhat = o.fhat[i]; r.wstar = o.wstar[i]; }
 }
@@ -632,5 +688,79 @@ __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ld
     }
   }
   // bias gradient: column sums of dY (waves whose lanes all sit beyond N skip the LDS reads)
+  if (wave * 64 < N) opt_step1<EWC, TGT>(o, offb + nb, bias_grad(dYs, ldy, nb), rb, tid < N);
+}
+
+// ---- the same epilogue with COMPILE-TIME trip counts (SNet shapes) ----
+// What the loop above loses: its vector-memory operations sit under conditions (`s + 2 < per`, predicated stores, the
+// tile-slot guards), so the compiler's s_waitcnt bookkeeping has to assume the path on which the fewest of them were
+// issued -- in the built kernel every tile waited with vmcnt(0), i.e. for the prefetches of the NEXT tiles as well, and
+// the two / three state sets bought nothing (round 3: the ISA showed it, and two sets measured like three).  Here the
+// tile slots are fully unrolled into one static schedule in which every slot issues exactly 7 (4) loads and 5 (3) stores
+// by ALL lanes:
+//  * lanes that own no parameter -- pad rows (n >= N) of the last strip, and in a short last k-block (kw < 16) the lanes
+//    beyond it -- take the place of a lane that does (the strip's last real row, lane group 0): same address, same state,
+//    the gradient fetched from that lane, the very same values stored a second time.  Identical addresses inside one wave
+//    access are one request, so the pad rows of the tile-major layout (12 of 112 rows of a 100-wide layer, 15 of 16 of a
+//    1-wide one: a quarter more state than there are parameters) are no longer READ either;
+//  * a wave's slots beyond the last tile are always its LAST ones: their loads go to a clamped address, products and stores
+//    are skipped under one uniform branch, which only blurs the counts of what follows the loop.
+// The waits inside the loop are then exact: before a tile's Adam step only ITS loads are awaited.
+// requested: sets 0 .. NSETS-2 were requested by the caller (bwd_net: ahead of the layer's input-gradient pass).
+template <int NSETS> struct OptCarry { OptRegs r[NSETS]; int i[NSETS]; int src[NSETS]; };
+
+// element index of lane (c, g)'s four parameters in tile slot p, and the lane whose gradient they take (itself, or
+// lane (c, 0) beyond a short k-block)
+__device__ __forceinline__ int dw_elem_u(int p, int total, int KT, int N, int kp, int offw, int c, int g, int &src) {
+  const int pc = p < total ? p : total - 1;
+  const int nt = pc / KT, kt = pc - nt * KT;
+  const int kw = ddrl_tile_kw(kt, kp);
+  const int gg = 4 * g < kw ? g : 0;
+  const int cc = nt * 16 + c < N ? c : N - 1 - nt * 16;      // pad rows of the last strip: the strip's last real row
+  src = 16 * gg + cc;
+  return offw + ddrl_tile_base(nt, kt, kp) + cc * kw + 4 * gg;
+}
+
+template <bool EWC, bool TGT, int NSETS>
+__device__ __forceinline__ void dw_opt_request(int N, int kp, int offw, const OptCtx &o, int wave, int lane, OptCarry<NSETS> &cy) {
+  const int g = lane >> 4, c = lane & 15;
+  const int NT = (N + 15) >> 4, KT = (kp + 15) >> 4, total = NT * KT;
+  const int per = (total + DDRL_NWAVES - 1) / DDRL_NWAVES, p0 = wave * per;
+#pragma unroll
+  for (int q = 0; q < NSETS - 1; ++q)
+    if (q < per) {
+      cy.i[q] = dw_elem_u(p0 + q, total, KT, N, kp, offw, c, g, cy.src[q]);
+      opt_load4<EWC, TGT>(o, cy.i[q], cy.r[q]);
+    }
+}
+
+template <bool EWC, bool TGT, int NSETS>
+__device__ __forceinline__ void bwd_dw_opt_ct(const float *__restrict__ dYs, int ldy, int N,
+                                              const float *__restrict__ Xs, int ldx, int kp,
+                                              int offw, int offb, const OptCtx &o,
+                                              int wave, int lane, int tid, OptCarry<NSETS> &cy, bool requested) {
+  const int g = lane >> 4, c = lane & 15;
+  const int NT = (N + 15) >> 4, KT = (kp + 15) >> 4, total = NT * KT;
+  const int per = (total + DDRL_NWAVES - 1) / DDRL_NWAVES, p0 = wave * per;
+  OptRegs1 rb;
+  const int nb = tid < N ? tid : N - 1;
+  opt_load1<EWC, TGT>(o, offb + nb, rb);
+  if (!requested) dw_opt_request<EWC, TGT, NSETS>(N, kp, offw, o, wave, lane, cy);
+#pragma unroll
+  for (int s = 0; s < per; ++s) {
+    if (s + NSETS - 1 < per) {
+      const int q = (s + NSETS - 1) % NSETS;
+      cy.i[q] = dw_elem_u(p0 + s + NSETS - 1, total, KT, N, kp, offw, c, g, cy.src[q]);
+      opt_load4<EWC, TGT>(o, cy.i[q], cy.r[q]);
+    }
+    const int q = s % NSETS;
+    if (p0 + s < total) {                      // uniform; false only for a wave's trailing slots
+      f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = __shfl(acc[e], cy.src[q]);
+      opt_step4<EWC, TGT, true, false>(o, cy.i[q], acc, cy.r[q], true);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (wave * 64 < N) opt_step1<EWC, TGT>(o, offb + nb, bias_grad(dYs, ldy, nb), rb, tid < N);
 }

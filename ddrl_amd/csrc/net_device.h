@@ -50,10 +50,94 @@ __device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry
   if (16 < nx.N) load_bfrag(W, bias, nx.kp, nx.N, 1, lane, cy.b1);
 }
 
-template <class ND>
+// ---- compile-time shapes: the whole pass as ONE static schedule ----
+// The rolled tile loop of fwd_layer keeps its weight-fragment loads under conditions, which costs the s_waitcnt
+// bookkeeping its precision (the built kernel waited with vmcnt(8): ONE fragment set in flight, not two), and it
+// requested a layer's first tiles only after the previous layer's last tile.  Here the tiles of all layers of the pass
+// form one sequence: tile j sits in fragment set j % 3, the loads for tile j + 2 are issued before tile j is computed,
+// across layer boundaries and -- HAS_AFTER -- into the first two tiles of the pass that follows.  Fully unrolled: every
+// guard folds, every vector-memory operation is unconditional, the waits are exact.
+// Hand-over convention (unchanged): a pass starts with its tiles 0 / 1 in cy.b0 / cy.b1; that is where this pass leaves
+// them for its successor when its tile count is a multiple of three (true for every instantiated net), else the successor
+// starts cold.
+template <class ND> __host__ __device__ constexpr int fwd_pass_tiles(int nl) {
+  int t = 0;
+  for (int l = 0; l < nl; ++l) t += (ND::d(l + 1) + 15) / 16;
+  return t;
+}
+template <class ND, bool HAS_AFTER>
+__device__ __forceinline__ void fwd_net_ct(const ND &nd, int nl, const float *__restrict__ w,
+                                           const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
+                                           int wave, int lane, FwdCarry &cy, bool preloaded, const FwdNext after) {
+  const int g = lane >> 4, c = lane & 15;
+  BFrag b2;
+  const float *wo = opaque(w);
+  const float *aW = HAS_AFTER ? opaque(after.W) : nullptr, *ab = HAS_AFTER ? opaque(after.bias) : nullptr;
+  const bool hand = HAS_AFTER && fwd_pass_tiles<ND>(nl) % 3 == 0;
+  // request tile `t` of layer `l` (or, past the last layer of the pass, of the successor) into fragment set `set`
+  auto request = [&](int l, int t, int set) {
+    // walk forward over layers whose tiles are exhausted (folds: every bound is a constant)
+    bool done = false;
+#pragma unroll
+    for (int step = 0; step <= DDRL_MAXL; ++step) {
+      if (!done && l < nl) {
+        const int NTl = (nd.d(l + 1) + 15) >> 4;
+        if (t < NTl) {
+          BFrag &dst = set == 0 ? cy.b0 : set == 1 ? cy.b1 : b2;
+          load_bfrag(wo + nd.offw(l), wo + nd.offb(l), nd.kp(l), nd.d(l + 1), t, lane, dst);
+          done = true;
+        } else { t -= NTl; ++l; }
+      }
+    }
+    if (!done && hand && l >= nl && t < 2 && t * 16 < after.N) {
+      BFrag &dst = set == 0 ? cy.b0 : set == 1 ? cy.b1 : b2;
+      load_bfrag(aW, ab, after.kp, after.N, t, lane, dst);
+    }
+  };
+  if (!preloaded) { request(0, 0, 0); request(0, 1, 1); }
+  const float *in = X;
+  int ldi = ldx, j = 0;
+#pragma unroll
+  for (int l = 0; l < nd.L(); ++l) {
+    if (l < nl) {
+      const bool last = l == nd.L() - 1;
+      float *out = last ? top : hbase + l * hstride;
+      const int ldo = last ? ldtop : nd.ld(l + 1);
+      const int N = nd.d(l + 1), kp = nd.kp(l), act = last ? nd.out_act() : nd.hidden_act();
+      const int NT = (N + 15) >> 4;
+      AFrag a;
+      load_afrag(in, ldi, kp, wave, lane, a);
+      float *yrow = out + (16 * wave + 4 * g) * ldo;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt, ++j) {
+        request(l, nt + 2, (j + 2) % 3);
+        const BFrag &b = j % 3 == 0 ? cy.b0 : j % 3 == 1 ? cy.b1 : b2;
+        const f32x4 acc = row_tile(a, b, kp);
+        const int n = nt * 16 + c;
+        if (n < ldo) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yrow[r * ldo + n] = n < N ? act_fwd(act, acc[r] + b.bias) : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wave_lds_fence();
+      in = out;
+      ldi = ldo;
+    }
+  }
+  ddrl_sync();
+}
+
+template <class ND, bool HAS_AFTER = true>
 __device__ __forceinline__ void fwd_net(const ND &nd, int nl, const float *__restrict__ w,
                                         const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                         int wave, int lane, FwdCarry &cy, bool preloaded, const FwdNext after) {
+#ifndef DDRL_NO_FWD_CT
+  if constexpr (!__is_same(ND, NetDesc)) {
+    fwd_net_ct<ND, HAS_AFTER>(nd, nl, w, X, ldx, hbase, hstride, top, ldtop, wave, lane, cy, preloaded, after);
+    return;
+  }
+#endif
   const float *in = X;
   int ldi = ldx;
 #pragma unroll
@@ -88,7 +172,7 @@ __device__ __forceinline__ void fwd_net(const ND &nd, int nl, const float *__res
                                         int wave, int lane) {
   FwdCarry cy;
   const FwdNext none = {nullptr, nullptr, 4, 1};
-  fwd_net(nd, nl, w, X, ldx, hbase, hstride, top, ldtop, wave, lane, cy, false, none);
+  fwd_net<ND, false>(nd, nl, w, X, ldx, hbase, hstride, top, ldtop, wave, lane, cy, false, none);
 }
 
 // Backward through a whole net from dZ_L held in `top` (diff w.r.t. the last InnerProduct's
@@ -99,6 +183,8 @@ __device__ __forceinline__ void fwd_net(const ND &nd, int nl, const float *__res
 // reduction over batch chunks.  nc > 0: the input gradient columns [c0, c0 + nc) are handed to
 // dx0_store(row, col - c0, value); the caller synchronises before other waves read what it wrote.
 enum { DW_NONE = 0, DW_OPT = 1, DW_STORE = 2 };
+template <class ND> struct KParkOf { static constexpr bool value = ND::kPark; };
+template <> struct KParkOf<NetDesc> { static constexpr bool value = false; };
 #define DDRL_PARK_TILES 4     // input-gradient tiles (of up to DDRL_MAXKC) parked in LDS during a deep layer's optimiser loop
 // TGT: the optimiser epilogue also moves the net's target twin (false: TD3's critics between two policy steps)
 template <int TRAIN, bool EWC, bool TGT = true, class ND, class DX0>
@@ -121,6 +207,20 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
     f32x4 acc[DDRL_MAXKC];
     int kt0 = 0, kt1 = (K + 15) >> 4;
     if (l == 0) { kt0 = c0 >> 4; kt1 = (c0 + nc + 15) >> 4; }
+    // compile-time shapes: the static optimiser schedule of mlp_device.h (bwd_dw_opt_ct); the state of the layer's first
+    // tile slots is requested HERE, ahead of the input-gradient pass, so that the tile loop does not start on a cold wait
+#ifdef DDRL_NO_OPT_CT
+    constexpr bool CT = false;
+#else
+    constexpr bool CT = !__is_same(ND, NetDesc) && TRAIN == DW_OPT;
+#endif
+    constexpr bool deep_ct = CT && KParkOf<ND>::value;
+    OptCarry<3> oc3;
+    OptCarry<2> oc2;
+    if constexpr (CT) {
+      if (deep_ct && l < nd.L() - 1) dw_opt_request<EWC, TGT, 3>(N, kp, nd.offw(l), opt, wave, lane, oc3);
+      else dw_opt_request<EWC, TGT, 2>(N, kp, nd.offw(l), opt, wave, lane, oc2);
+    }
     if (need_dx) bwd_dx(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
     if (bst && tid == 0 && ll < 2) bst[2 * ll] = clock64();
     if (TRAIN != DW_NONE) {
@@ -129,14 +229,23 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
         // Below the top layer the first DDRL_PARK_TILES input-gradient tiles wait in LDS while the
         // optimiser loop runs, which makes room for its third state set (the first layer has no
         // input gradient at all).  Wave-private: no barrier, only the wave's own LDS ordering.
+#ifdef DDRL_EXP_SETS2      // measurement: two optimiser state sets everywhere (how much does the third one buy?)
+        const bool deep = false;
+#else
         const bool deep = park != nullptr && l < nd.L() - 1;
+#endif
         if (deep && need_dx) {
 #pragma unroll
           for (int i = 0; i < DDRL_PARK_TILES; ++i)
             if (kt0 + i < kt1) *(f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4) = acc[i];
         }
-        if (deep) bwd_dw_opt<EWC, TGT, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
-        else bwd_dw_opt<EWC, TGT, false>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+        if constexpr (CT) {
+          if (deep_ct && l < nd.L() - 1) bwd_dw_opt_ct<EWC, TGT, 3>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid, oc3, true);
+          else bwd_dw_opt_ct<EWC, TGT, 2>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid, oc2, true);
+        } else {
+          if (deep) bwd_dw_opt<EWC, TGT, true>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+          else bwd_dw_opt<EWC, TGT, false>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid);
+        }
         if (deep && need_dx) {
 #pragma unroll
           for (int i = 0; i < DDRL_PARK_TILES; ++i)

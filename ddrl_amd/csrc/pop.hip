@@ -28,6 +28,9 @@ hipError_t replay_append_launch(float *rep, int *len, int *head, int G, int cap,
                                 const float *s, const float *a, const float *r, const float *s2,
                                 const uint8_t *goal, const uint8_t *mask, hipStream_t st);
 int ddpg_update_pair_pays(const DdpgParams *P);
+int ddpg_update_loop_ok(const DdpgParams *P);
+int ddpg_update_loop_pays(const DdpgParams *P);
+hipError_t ddpg_update_loop_launch(const DdpgParams *P, hipStream_t st);
 hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st);
 size_t ddpg_update_bn_lds_bytes(const DdpgParams *P);
 hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G, hipStream_t st);
@@ -690,7 +693,11 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   // and the small nets' update is bound by its chain of tiny dependent passes, not by HBM: DESIGN.md section 4.1e)
   const bool resident = fused && !h->force_generic && h->resident_mode > 0 && per_launch >= 2 &&
                         !h->P.stamps && ddpg_update_resident_ok(&h->P);
-  h->P.pair = pair || resident ? 1 : 0;
+  // the default for multi-update launches of the compile-time shapes: one workgroup walks its agent through the launch
+  // (ddpg_update_loop_kernel); option "loop" 0 falls back to one workgroup per (update, agent) with the sc1 hand-off
+  const bool loop = fused && !h->force_generic && h->loop_mode > 0 && per_launch >= 2 && !pair && !resident && ddpg_update_loop_ok(&h->P) &&
+                    (h->loop_mode == 2 || ddpg_update_loop_pays(&h->P));
+  h->P.pair = pair || resident || loop ? 1 : 0;
   std::vector<int32_t> one;
   for (int l = 0; l < n; l += per_launch) {
     if (idx) {
@@ -723,6 +730,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
     else if (!fused) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
     else if (resident) HIPCHK(ddpg_update_resident_launch(&h->P, h->stream));
     else if (pair) HIPCHK(ddpg_update_pair_launch(&h->P, h->stream));
+    else if (loop) HIPCHK(ddpg_update_loop_launch(&h->P, h->stream));
     else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
     if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   }
@@ -1177,6 +1185,7 @@ extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
   if (std::string(key) == "force_generic") { h->force_generic = value != 0; return DDRL_OK; }
   if (std::string(key) == "nfac_fuse") { h->nfac_fuse = value != 0; return DDRL_OK; }
   if (std::string(key) == "resident") { h->resident_mode = value != 0; return DDRL_OK; }
+  if (std::string(key) == "loop") { h->loop_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "pair") { h->pair_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "force_chunked") {     // the gradient + apply kernels of the large-minibatch path on one-tile minibatches
     DDPG_ONLY(h);

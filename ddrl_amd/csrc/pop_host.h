@@ -82,7 +82,7 @@ struct ddrl_pop {
   bool multi_pending = false;   // a multi-update launch was issued since the error word was last read (ddrl_pop_wait)
   int resident_mode = 0;      // 1: small nets keep an agent's whole state in LDS for a multi-update launch (ddpg_update_resident_kernel)
   int nfac_fuse = 0;          // NFAC, option "nfac_fuse": 1 = the optimiser step inside the gradient launch (bit-identical; measured SLOWER, kernels_nfac.hip), 0 = separate nfac_apply_kernel launches
-  int pair_mode = 1;          // 0: never the two-agents-per-workgroup kernel, 1: for launches of >= DDRL_PAIR_MIN_UPD updates, 2: whenever it fits
+  int pair_mode = 0;          // 0: never the two-agents-per-workgroup kernel (the default since round 3: the loop kernel is faster), 1: for launches of >= DDRL_PAIR_MIN_UPD updates where pairs paid in round 2, 2: whenever it fits
   bool force_chunked = false;
   bool wide = false;               // some layer is wider than DDRL_MAXW: layer-by-layer update kernels
   bool bn = false;                 // some net has BatchNorm towers: kernels_ddpg_bn.hip
@@ -90,6 +90,7 @@ struct ddrl_pop {
   double beta1 = 0., beta2 = 0.999;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
+  int loop_mode = 1;          // multi-update launches keep an agent's updates in one workgroup (ddpg_update_loop_kernel): 0 never, 1 where it pays (mid nets), 2 whenever the shapes are compile-time ones
 };
 
 #define HIPCHK(expr)                                                                        \

@@ -373,16 +373,24 @@ def test_xcd_order_many_agents(ora, G, B, hidden_a, hidden_q):
         check_step(pop, agents, ws_prev, _hyper(agents), 0, TOL, allow_kink=True)
 
 
-@pytest.mark.parametrize("pair", [1, 0])
+def _multi_update_mode(pop, mode):
+    """which kernel runs a multi-update launch of the compile-time shapes: the in-workgroup loop (the default for mid nets),
+    agent pairs, or one workgroup per (update, agent) with the sc1 hand-off"""
+    pop.set_option("loop", {"loop": 2, "pair": 0, "handoff": 0}[mode])
+    pop.set_option("pair", {"loop": 0, "pair": 2, "handoff": 0}[mode])
+
+
+@pytest.mark.parametrize("pair", ["loop", "pair", "handoff"])
 @pytest.mark.parametrize("B,hidden,kw", [(64, (100, 100), dict()), (32, (20,), dict(nstep_return=2, goal_prob=0.1)), (96, (24, 16), dict())])
 def test_fused_consecutive_updates(ora, B, hidden, kw, pair):
     """ddrl_pop_ddpg_update_n: n passes of the fupd loop in one launch (one-tile minibatches) == n calls of
     ddrl_pop_ddpg_update, bit for bit, including the replay-index stream; and against the oracle.  pair = 1: launches
-    of >= 4 updates of the compile-time shapes run as agent pairs (kernels_ddpg_pair.hip; G = 3 leaves one team
-    without an agent, the mask another one idle); pair = 0: one workgroup per (update, agent) with the sc1 hand-off."""
+    of the compile-time shapes run as agent pairs (kernels_ddpg_pair.hip; G = 3 leaves one team without an agent, the
+    mask another one idle); "handoff": one workgroup per (update, agent) with the sc1 hand-off; "loop": one workgroup walks its
+    agent through the launch (ddpg_update_loop_kernel, the default for mid nets)."""
     G, n = 3, 4
     popa, agents = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
-    popa.set_option("pair", pair)
+    _multi_update_mode(popa, pair)
     popb, _ = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
     mask = np.array([1, 0, 1], np.uint8)
     popa.update_n(n, mask=mask)
@@ -453,7 +461,7 @@ def test_resident_small_nets(ora, ewc):
     assert list(popa.adam(0)[2]) == [1 + 2 * n, 1 + 2 * n, 1, 1 + 2 * n, 1 + 2 * n]
 
 
-@pytest.mark.parametrize("pair", [1, 0])
+@pytest.mark.parametrize("pair", ["loop", "pair", "handoff"])
 def test_fused_consecutive_updates_full_chip(pair):
     """the same identity at the bench's scale, EWC live.  pair = 0: 8 x 1100 workgroups against 512 resident slots, so
     an agent's consecutive updates run in different dispatch rounds, on different CUs and XCDs (the sc1 hand-off);
@@ -476,7 +484,7 @@ def test_fused_consecutive_updates_full_chip(pair):
         p.update_best_param(np.ones(G)); p.ewc_setup()
         pops.append(p)
     a, b = pops
-    a.set_option("pair", pair)
+    _multi_update_mode(a, pair)
     for _ in range(2):
         a.update_n(n)
         for _ in range(n):
