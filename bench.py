@@ -149,7 +149,9 @@ def free_port():
 def launch_ranks(n):
     """`python bench.py --gpus N` without torch.distributed.run: this process never touches the GPU; it starts N
     fresh interpreters, one per GPU, and relays rank 0's line.  (The other way round -- re-executing a process
-    that has initialised HIP -- is what must never happen.)"""
+    that has initialised HIP -- is what must never happen.)  Every child is polled: when one exits non-zero the others
+    (which would sit in the rendezvous or a barrier until the collective library's timeout) are terminated -- they are
+    fresh children of this launcher, nothing is re-executed -- and the launcher exits non-zero naming the rank."""
     port = os.environ.get("MASTER_PORT") or str(free_port())
     procs = []
     for r in range(n):
@@ -157,14 +159,39 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, DDRL_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed: %s\n" % ", ".join("rank %d exit %d" % rc for rc in bad))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # never blocks the polling below
+    reader.start()
+    first_bad = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            first_bad = bad
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    if first_bad:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        failed = set(r for r, _ in first_bad)
+        sys.stderr.write("bench.py: ranks failed: %s; final status: %s\n" % (
+            ", ".join("rank %d exit %d" % rc for rc in first_bad),
+            ", ".join("rank %d exit %d%s" % (r, p.returncode, "" if r in failed or p.returncode == 0 else " (terminated by the launcher)")
+                      for r, p in enumerate(procs))))
         sys.exit(1)
+    reader.join(timeout=10)
+    sys.stdout.write((out0[0] if out0 else b"").decode())
+    sys.stdout.flush()
 
 
 def build_population(G, rank, first_agent, S, A, B, ha, hq, ewc, replay, local_rank):
@@ -260,13 +287,19 @@ def nfac_cpu_baseline(seconds, threads):
 
 
 def nfac_main(args, rank, local_rank, world):
+    out = nfac_measure(args, rank, local_rank, world)
+    if out is not None:
+        print(json.dumps(out))
+
+
+def nfac_measure(args, rank, local_rank, world, cpu_leg=True):
     """--workload nfac: SURVEY.md 8(d) config 3.  A step = one NFAC(lambda)-V update (OfflineCaclaAg::end_episode's learning
     branch, OfflineCaclaAg.hpp:423-594) of every agent on this GPU: 10 fitted iterations x 10 full-batch critic steps + 10
     actor steps on a 500-row trajectory, EWC live on both nets.  Agents are sharded over ranks, no collective."""
     c = NFAC
     G = args.agents if args.agents != 1024 else 256
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and cpu_leg:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         ups, n, dt = nfac_cpu_baseline(args.cpu_seconds, threads)
         cpu = {"value": ups, "unit": "agent updates/s", "cores": threads, "kind": "port", "host_cpu_count": os.cpu_count(),
@@ -317,11 +350,11 @@ def nfac_main(args, rank, local_rank, world):
         dt = float(t.item())
         dist.destroy_process_group()
     if rank != 0:
-        return
+        return None
     Pw = c["S"] * 64 + 64 * 64 + 64                       # the critic's weights
     flops_launch = G * c["T"] * (4 * Pw + 2 * (64 * 64 + 64))   # forward + dW over all layers, dX below the first: 2 flop / MAC
     kavg = kernel_ms * 1e-3 / max(launches, 1)
-    print(json.dumps({
+    return ({
         "metric": "NFAC(lambda)-V agent updates/sec (config 3)", "value": world * G * steps / dt, "unit": "agent updates/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -334,7 +367,89 @@ def nfac_main(args, rank, local_rank, world):
                      "kernel": "nfac_grad_kernel<0, ...> (the critic's full-batch gradient: %d of the %d launches of an update)"
                                % (c["fitted"] * c["critic_steps"], 2 * c["fitted"] * c["critic_steps"] + 2 * c["actor_steps"] + 3 * c["fitted"] + 4),
                      "kernel_avg_ms": kavg * 1e3, "launches": launches, "algorithmic_flops_per_launch": flops_launch},
-        "cpu_baseline": cpu}))
+        "cpu_baseline": cpu})
+
+
+def cmaes_measure(N, lam, dev, gens):
+    """SURVEY.md 8(d) config 4 on one GPU (tools/bench_cmaes.py): generations / s of CMA-ES at dimension N, lambda individuals,
+    synthetic quadratic fitness.  dev False = parity mode (c-cmaes' own random stream + the host Householder / QL
+    eigendecomposition, bit-identical to the goldens), True = throughput mode (device RNG, device eigensolver, device fitness)"""
+    import torch
+    import ddrl_amd
+    es = ddrl_amd.Cmaes(np.full(N, 0.1), np.full(N, 0.3), 3, lam)
+    es.set_option("device_rng", int(dev)); es.set_option("device_eigen", int(dev))
+    target = torch.linspace(-0.5, 0.5, N, device="cuda", dtype=torch.float64) if dev else np.linspace(-0.5, 0.5, N)
+    ts = []
+    for g in range(gens):
+        t0 = time.perf_counter()
+        if dev:
+            es.sample_dev()
+            f = ((es.population_torch().double() - target) ** 2).sum(1)
+            torch.cuda.synchronize()
+            es.update_dev(f.data_ptr())
+        else:
+            X = es.sample()
+            es.update(((X - target) ** 2).sum(1))
+        es.get("sigma")
+        ts.append(time.perf_counter() - t0)
+    es.close()
+    per = float(np.median(ts))
+    flops = 2.0 * lam * N * N + 2.0 * (lam // 2) * N * N
+    return {"generations_per_s": 1.0 / per, "ms_per_generation": per * 1e3, "mfma_f32_frac_whole_generation": flops / per / MFMA_F32_PEAK}
+
+
+def extra_measurements(args, S, A, B, ewc, upl, barrier, budget_s=75.0):
+    """The secondary configurations on the driver's record (N = 1 only, after the headline sweep, outside its timed region):
+    the metric's own per-GPU share of a node (128 agents), the small and large nets, NFAC config 3, CMA-ES config 4.  Each
+    entry is its own short sweep of the same kind as the headline one; an entry that would overrun the budget is skipped and
+    says so."""
+    t_start = time.perf_counter()
+    out = {}
+
+    def left():
+        return budget_s - (time.perf_counter() - t_start)
+
+    def ddpg_entry(name, G, size, steps, warmup, replay):
+        if left() < 8:
+            out[name] = {"skipped": "time budget"}
+            return
+        ha, hq = SIZES[size]
+        u = upl if max(ha + hq) <= 128 else 1
+        pop = build_population(G, 0, 0, S, A, B, ha, hq, ewc, replay, 0)
+        dt, kms, launches = timed_sweep(pop, G, steps, warmup, u, ewc, barrier)
+        del pop
+        byts, flops, _, _ = algorithmic_work(S, A, B, ha, hq, ewc)
+        kavg = kms * 1e-3 / max(launches, 1)
+        upl_eff = steps / max(launches, 1)
+        out[name] = {"workload": "%d agents, %s nets, replay %d/agent, %d updates per launch" % (G, size, replay, u),
+                     "value": G * steps / dt, "unit": "updates/s", "ms_per_step": dt / steps * 1e3,
+                     "hbm_frac": byts * G * upl_eff / kavg / HBM_PEAK, "mfma_f32_frac": flops * G * upl_eff / kavg / MFMA_F32_PEAK}
+
+    try:
+        ddpg_entry("agents128", 128, "mid", 96, 16, args.replay)
+        ddpg_entry("small", 1024, "small", 96, 16, 2000)
+        ddpg_entry("large", 1024, "large", 16, 4, 2000)
+        if left() > 12:
+            class _A:                                   # the NFAC sweep's arguments
+                agents, steps, warmup, no_cpu, cpu_threads, cpu_seconds = 1024, 4, 1, True, 0, 0.0
+            n = nfac_measure(_A, 0, 0, 1, cpu_leg=False)
+            out["nfac"] = {"workload": n["config"]["workload"], "value": n["value"], "unit": n["unit"], "ms_per_update": n["ms_per_step"],
+                           "mfma_f32_frac_gradient_launch": n["roofline"]["frac"]}
+        else:
+            out["nfac"] = {"skipped": "time budget"}
+        cm = {}
+        for N in (151, 631):
+            for dev in (False, True):
+                key = "N%d_%s" % (N, "throughput" if dev else "parity")
+                if left() < (6 if N == 631 else 3):
+                    cm[key] = {"skipped": "time budget"}
+                    continue
+                cm[key] = cmaes_measure(N, 4096, dev, 6 if dev else 4)
+        out["cmaes"] = dict(cm, workload="config 4: CMA-ES lambda=4096 mu=2048 on one GPU, synthetic quadratic fitness")
+    except Exception as e:                               # the headline line must not be lost to a secondary sweep
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    out["seconds"] = time.perf_counter() - t_start
+    return out
 
 
 def main():
@@ -353,6 +468,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sweep")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the secondary configurations (`extra` in the JSON line)")
     ap.add_argument("--pair", type=int, default=0, help="0: one agent per workgroup always (default); 1: agent pairs for launches of >= 4 updates; 2: pairs whenever they fit")
     ap.add_argument("--loop", type=int, default=1, help="multi-update launches keep an agent's updates in one workgroup (ddpg_update_loop_kernel): 1 where it pays (mid nets), 2 always, 0: one workgroup per (update, agent)")
     ap.add_argument("--resident", type=int, default=0, help="1: small nets keep an agent's state in LDS over a multi-update launch")
@@ -399,6 +515,8 @@ def main():
     import torch
     import torch.distributed as dist
     if args.dry_run:
+        if os.environ.get("DDRL_BENCH_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+            sys.exit(3)
         if world > 1:
             dist.init_process_group("gloo")
         t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
@@ -482,6 +600,8 @@ def main():
     }
     if strong is not None:
         out["strong"] = strong
+    if world == 1 and not args.no_extra and args.size == "mid" and G == 1024:
+        out["extra"] = extra_measurements(args, S, A, B, ewc, upl, barrier)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -130,7 +130,7 @@ __device__ __forceinline__ float act_bwd(int t, float y, float dy) {
 // of W, columns kc*16 + 4g .. + 3 for every 16-deep k-chunk kc.  Requested in one burst so the
 // L2/HBM latency is paid once per tile; callers request the NEXT tile's fragments (also across a
 // layer boundary: weights do not depend on activations) before computing the current one.
-struct BFrag { f32x4 v[DDRL_MAXKC]; float bias; };   // + the tile's bias: waiting for it separately would drain the prefetches (loads retire in order)
+struct BFrag { f32x4 v[DDRL_MAXKC]; float bias; float t[3]; };   // + the tile's bias: waiting for it separately would drain the prefetches (loads retire in order); t: short-tail operands (below)
 
 __device__ __forceinline__ void load_bfrag(const float *__restrict__ W, const float *__restrict__ bias, int kp, int N, int nt, int lane, BFrag &b) {
   const int g = lane >> 4, c = lane & 15;
@@ -165,7 +165,8 @@ static_assert(DDRL_NWAVES * 16 == DDRL_MB, "row-parallel passes: one 16-row tile
 // kc*16 + 4g .. + 3 for every 16-deep k-chunk.  Columns >= kp are zeroed HERE (one LDS-side select per
 // layer), so the weight fragments they meet need no masking: masking a prefetched global load would
 // force a wait for it right where it is issued.
-struct AFrag { f32x4 v[DDRL_MAXKC]; };
+struct AFrag { f32x4 v[DDRL_MAXKC]; float t[3]; };
+struct WCol { float v[DDRL_MAXKC][4]; float t[3]; };     // the weight fragments of an input-gradient tile (load_wcol)
 
 __device__ __forceinline__ void load_afrag(const float *__restrict__ Xs, int ldx, int kp, int wave, int lane, AFrag &a) {
   const int g = lane >> 4, c = lane & 15;
@@ -194,6 +195,110 @@ __device__ __forceinline__ f32x4 row_tile(const AFrag &a, const BFrag &b, int kp
       }
     }
   }
+  return acc0 + acc1;
+}
+
+// ---- SHORT TAIL (compile-time shapes) ----
+// A contraction of length kp = 16 F + T (T = 4, 8 or 12) costs 4 (F + 1) MFMAs in the layout above: the last chunk's
+// four products carry one valid k each in slot group g = 0 (or two, ...) and zeros elsewhere.  The short-tail forms give
+// the last chunk its own slot mapping -- product e' of the tail, slot g <-> k = 16 F + 4 e' + g -- so that it takes T / 4
+// products: kp / 4 in all, the minimum (100-deep: 25 instead of 28; 20-deep: 5 instead of 8).  The tail operands are
+// single dwords: X[row c][16 F + 4 e' + g] from LDS, W[n c][16 F + 4 e' + g] (a contiguous 256-B wave access of the
+// [16 x T] block) or, for input gradients, W[16 F + 4 e' + g][k c].  The k-sum of a tail runs over the four slots of one
+// product instead of over four products: the same terms in another order (results move in the last bit).
+__host__ __device__ constexpr int st_full(int kp) { return kp / 16; }
+__host__ __device__ constexpr int st_ntail(int kp) { return (kp - 16 * (kp / 16)) / 4; }
+
+__device__ __forceinline__ void load_afrag_st(const float *__restrict__ Xs, int ldx, int kp, int wave, int lane, AFrag &a) {
+  const int g = lane >> 4, c = lane & 15;
+  const float *row = Xs + (16 * wave + c) * ldx;
+#pragma unroll
+  for (int kc = 0; kc < DDRL_MAXKC; ++kc)
+    if (kc < st_full(kp)) a.v[kc] = *(const f32x4 *)(row + kc * 16 + 4 * g);
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (e < st_ntail(kp)) a.t[e] = row[16 * st_full(kp) + 4 * e + g];
+}
+
+__device__ __forceinline__ void load_bfrag_st(const float *__restrict__ W, const float *__restrict__ bias, int kp, int N, int nt, int lane, BFrag &b) {
+  const int g = lane >> 4, c = lane & 15;
+#ifdef DDRL_EXP_NOWLOAD
+  b.bias = 0.01f * nt;
+#pragma unroll
+  for (int kc = 0; kc < DDRL_MAXKC; ++kc) b.v[kc] = (f32x4){0.01f * (float)lane, 0.02f, -0.01f * (float)kc, 0.03f};
+  b.t[0] = b.t[1] = b.t[2] = 0.01f;
+  return;
+#endif
+  b.bias = bias[nt * 16 + c < N ? nt * 16 + c : N - 1];
+#pragma unroll
+  for (int kc = 0; kc < DDRL_MAXKC; ++kc)
+    if (kc < st_full(kp)) b.v[kc] = *(const f32x4 *)(W + ddrl_tile_base(nt, kc, kp) + c * 16 + 4 * g);
+  const int tw = kp - 16 * st_full(kp);
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (e < st_ntail(kp)) b.t[e] = W[ddrl_tile_base(nt, st_full(kp), kp) + c * tw + 4 * e + g];
+}
+
+__device__ __forceinline__ f32x4 row_tile_st(const AFrag &a, const BFrag &b, int kp) {
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+  for (int kc = 0; kc < DDRL_MAXKC; kc += 2) {
+    if (kc < st_full(kp)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = mfma16(a.v[kc][e], b.v[kc][e], acc0);
+        if (kc + 1 < st_full(kp)) acc1 = mfma16(a.v[kc + 1][e], b.v[kc + 1][e], acc1);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (e < st_ntail(kp)) { if (e & 1) acc0 = mfma16(a.t[e], b.t[e], acc0); else acc1 = mfma16(a.t[e], b.t[e], acc1); }
+  return acc0 + acc1;
+}
+
+// input gradients: the contraction runs over the layer's N outputs (np = roundup(N, 4) = 16 F + T)
+__device__ __forceinline__ void load_wcol_st(const float *__restrict__ W, int kp, int N, int kt, int lane, WCol &b) {
+  const int g = lane >> 4, c = lane & 15;
+#ifdef DDRL_EXP_NOWLOAD
+#pragma unroll
+  for (int nc = 0; nc < DDRL_MAXKC; ++nc)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.v[nc][j] = 0.01f * (float)(lane + j) - 0.02f * (float)kt;
+  b.t[0] = b.t[1] = b.t[2] = 0.01f;
+  return;
+#endif
+  const int np = ddrl_roundup(N, 4);
+  const int kw = ddrl_tile_kw(kt, kp);
+  const int cc = c < kw ? c : kw - 1;
+#pragma unroll
+  for (int nc = 0; nc < DDRL_MAXKC; ++nc)
+    if (nc < st_full(np)) {
+      const float *blk = W + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + cc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b.v[nc][j] = blk[j * kw];
+    }
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (e < st_ntail(np)) b.t[e] = W[ddrl_tile_base(st_full(np), kt, kp) + (4 * e + g) * kw + cc];
+}
+
+__device__ __forceinline__ f32x4 dx_tile_st(const AFrag &a, const WCol &b, int N) {
+  const int np = ddrl_roundup(N, 4);
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+  for (int nc = 0; nc < DDRL_MAXKC; nc += 2) {
+    if (nc < st_full(np)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = mfma16(a.v[nc][e], b.v[nc][e], acc0);
+        if (nc + 1 < st_full(np)) acc1 = mfma16(a.v[nc + 1][e], b.v[nc + 1][e], acc1);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (e < st_ntail(np)) { if (e & 1) acc0 = mfma16(a.t[e], b.t[e], acc0); else acc1 = mfma16(a.t[e], b.t[e], acc1); }
   return acc0 + acc1;
 }
 
@@ -274,7 +379,6 @@ __device__ __forceinline__ void fwd_layer(const float *__restrict__ Xs, int ldx,
 // dX[rows of this wave][cols] = dY W for the column tiles kt in [kt0, kt1), kept in registers
 // (acc[kt - kt0]).  dYs: LDS, columns [N, roundup(N,4)) hold zeros.  B operand of tile (nc, kt): lane
 // (c, g) supplies W[nc*16 + 4g + j][kt*16 + c], four dword loads inside one contiguous 1-KiB block.
-struct WCol { float v[DDRL_MAXKC][4]; };
 
 __device__ __forceinline__ void load_wcol(const float *__restrict__ W, int kp, int N, int kt, int lane, WCol &b) {
   const int g = lane >> 4, c = lane & 15;
@@ -315,11 +419,32 @@ __device__ __forceinline__ f32x4 dx_tile(const AFrag &a, const WCol &b, int N) {
   return acc0 + acc1;
 }
 
+template <bool ST = false>     // ST: the short-tail forms (compile-time shapes)
 __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, int N,
                                        const float *__restrict__ W, int kp, int kt0, int kt1,
                                        f32x4 (&acc)[DDRL_MAXKC], int wave, int lane) {
   W = opaque(W);
   AFrag a;
+  if (ST) {
+    load_afrag_st(dYs, ldy, ddrl_roundup(N, 4), wave, lane, a);
+    WCol b0, b1;
+    if (kt0 < kt1) load_wcol_st(W, kp, N, kt0, lane, b0);
+#pragma unroll
+    for (int i = 0; i < DDRL_MAXKC; i += 2) {
+      const int kt = kt0 + i;
+      if (kt < kt1) {
+        if (kt + 1 < kt1) load_wcol_st(W, kp, N, kt + 1, lane, b1);
+        acc[i] = dx_tile_st(a, b0, N);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < kt1) {
+          if (kt + 2 < kt1) load_wcol_st(W, kp, N, kt + 2, lane, b0);
+          acc[i + 1] = dx_tile_st(a, b1, N);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    return;
+  }
   load_afrag(dYs, ldy, ddrl_roundup(N, 4), wave, lane, a);
 #ifdef DDRL_DX_SETS3
   {
@@ -584,6 +709,37 @@ __device__ __forceinline__ f32x4 dw_tile(const float *__restrict__ dYs, int ldy,
   return acc0 + acc1;
 }
 
+// the same tile with ALL 32 LDS operands requested before the first product (the compiler, left alone, puts every pair
+// of products behind its own ds_read2 + wait: eight LDS round trips per tile instead of one).  Used by the static
+// schedule of bwd_dw_opt_ct, where the tile's products are no longer hidden behind a vmcnt(0) wait.
+__device__ __forceinline__ f32x4 dw_tile_pre(const float *__restrict__ dYs, int ldy, int N,
+                                             const float *__restrict__ Xs, int ldx, int kp,
+                                             int p, int total, int KT, int c, int g) {
+  const int pc = p < total ? p : total - 1;
+  const int nt = pc / KT, kt = pc - nt * KT;
+  const int bn = nt * 16 + c, ak = kt * 16 + c;
+  const float *xa = Xs + (ak < kp ? ak : kp - 1) + 4 * g * ldx;
+  const float *yb = dYs + (bn < N ? bn : N - 1) + 4 * g * ldy;
+  float xv[16], yv[16];
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xv[mc * 4 + j] = xa[(mc * 16 + j) * ldx];
+      yv[mc * 4 + j] = yb[(mc * 16 + j) * ldy];
+    }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+  for (int mc = 0; mc < 4; mc += 2)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc0 = mfma16(xv[mc * 4 + j], yv[mc * 4 + j], acc0);
+      acc1 = mfma16(xv[(mc + 1) * 4 + j], yv[(mc + 1) * 4 + j], acc1);
+    }
+  return acc0 + acc1;
+}
+
 // db[n] = sum over the 64 rows of dY[:, n]: four interleaved partial sums so the LDS reads pipeline
 __device__ __forceinline__ float bias_grad(const float *__restrict__ dYs, int ldy, int n) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -707,7 +863,7 @@ __device__ __forceinline__ void bwd_dw_opt(const float *__restrict__ dYs, int ld
 //    are skipped under one uniform branch, which only blurs the counts of what follows the loop.
 // The waits inside the loop are then exact: before a tile's Adam step only ITS loads are awaited.
 // requested: sets 0 .. NSETS-2 were requested by the caller (bwd_net: ahead of the layer's input-gradient pass).
-template <int NSETS> struct OptCarry { OptRegs r[NSETS]; int i[NSETS]; int src[NSETS]; };
+template <int NSETS> struct OptCarry { OptRegs r[NSETS]; };      // (a slot's element index / source lane are recomputed at its use: cheaper than keeping them)
 
 // element index of lane (c, g)'s four parameters in tile slot p, and the lane whose gradient they take (itself, or
 // lane (c, 0) beyond a short k-block)
@@ -729,8 +885,8 @@ __device__ __forceinline__ void dw_opt_request(int N, int kp, int offw, const Op
 #pragma unroll
   for (int q = 0; q < NSETS - 1; ++q)
     if (q < per) {
-      cy.i[q] = dw_elem_u(p0 + q, total, KT, N, kp, offw, c, g, cy.src[q]);
-      opt_load4<EWC, TGT>(o, cy.i[q], cy.r[q]);
+      int src;
+      opt_load4<EWC, TGT>(o, dw_elem_u(p0 + q, total, KT, N, kp, offw, c, g, src), cy.r[q]);
     }
 }
 
@@ -749,16 +905,21 @@ __device__ __forceinline__ void bwd_dw_opt_ct(const float *__restrict__ dYs, int
 #pragma unroll
   for (int s = 0; s < per; ++s) {
     if (s + NSETS - 1 < per) {
-      const int q = (s + NSETS - 1) % NSETS;
-      cy.i[q] = dw_elem_u(p0 + s + NSETS - 1, total, KT, N, kp, offw, c, g, cy.src[q]);
-      opt_load4<EWC, TGT>(o, cy.i[q], cy.r[q]);
+      int src;
+      opt_load4<EWC, TGT>(o, dw_elem_u(p0 + s + NSETS - 1, total, KT, N, kp, offw, c, g, src), cy.r[(s + NSETS - 1) % NSETS]);
     }
     const int q = s % NSETS;
     if (p0 + s < total) {                      // uniform; false only for a wave's trailing slots
+#ifdef DDRL_DW_PRE
+      f32x4 acc = dw_tile_pre(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
+#else
       f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
+#endif
+      int src;
+      const int i = dw_elem_u(p0 + s, total, KT, N, kp, offw, c, g, src);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = __shfl(acc[e], cy.src[q]);
-      opt_step4<EWC, TGT, true, false>(o, cy.i[q], acc, cy.r[q], true);
+      for (int e = 0; e < 4; ++e) acc[e] = __shfl(acc[e], src);
+      opt_step4<EWC, TGT, true, false>(o, i, acc, cy.r[q], true);
     }
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -44,10 +44,10 @@ __device__ __forceinline__ FwdNext fwd_first(const ND &nd, const float *__restri
   FwdNext nx = {w + nd.offw(0), w + nd.offb(0), nd.kp(0), nd.d(1)};
   return nx;
 }
-__device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry &cy) {
+__device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry &cy) {     // (compile-time shapes only: the short-tail fragment form)
   const float *W = opaque(nx.W), *bias = opaque(nx.bias);
-  load_bfrag(W, bias, nx.kp, nx.N, 0, lane, cy.b0);
-  if (16 < nx.N) load_bfrag(W, bias, nx.kp, nx.N, 1, lane, cy.b1);
+  load_bfrag_st(W, bias, nx.kp, nx.N, 0, lane, cy.b0);
+  if (16 < nx.N) load_bfrag_st(W, bias, nx.kp, nx.N, 1, lane, cy.b1);
 }
 
 // ---- compile-time shapes: the whole pass as ONE static schedule ----
@@ -84,14 +84,14 @@ __device__ __forceinline__ void fwd_net_ct(const ND &nd, int nl, const float *__
         const int NTl = (nd.d(l + 1) + 15) >> 4;
         if (t < NTl) {
           BFrag &dst = set == 0 ? cy.b0 : set == 1 ? cy.b1 : b2;
-          load_bfrag(wo + nd.offw(l), wo + nd.offb(l), nd.kp(l), nd.d(l + 1), t, lane, dst);
+          load_bfrag_st(wo + nd.offw(l), wo + nd.offb(l), nd.kp(l), nd.d(l + 1), t, lane, dst);
           done = true;
         } else { t -= NTl; ++l; }
       }
     }
     if (!done && hand && l >= nl && t < 2 && t * 16 < after.N) {
       BFrag &dst = set == 0 ? cy.b0 : set == 1 ? cy.b1 : b2;
-      load_bfrag(aW, ab, after.kp, after.N, t, lane, dst);
+      load_bfrag_st(aW, ab, after.kp, after.N, t, lane, dst);
     }
   };
   if (!preloaded) { request(0, 0, 0); request(0, 1, 1); }
@@ -106,13 +106,13 @@ __device__ __forceinline__ void fwd_net_ct(const ND &nd, int nl, const float *__
       const int N = nd.d(l + 1), kp = nd.kp(l), act = last ? nd.out_act() : nd.hidden_act();
       const int NT = (N + 15) >> 4;
       AFrag a;
-      load_afrag(in, ldi, kp, wave, lane, a);
+      load_afrag_st(in, ldi, kp, wave, lane, a);
       float *yrow = out + (16 * wave + 4 * g) * ldo;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt, ++j) {
         request(l, nt + 2, (j + 2) % 3);
         const BFrag &b = j % 3 == 0 ? cy.b0 : j % 3 == 1 ? cy.b1 : b2;
-        const f32x4 acc = row_tile(a, b, kp);
+        const f32x4 acc = row_tile_st(a, b, kp);
         const int n = nt * 16 + c;
         if (n < ldo) {
 #pragma unroll
@@ -221,7 +221,7 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
       if (deep_ct && l < nd.L() - 1) dw_opt_request<EWC, TGT, 3>(N, kp, nd.offw(l), opt, wave, lane, oc3);
       else dw_opt_request<EWC, TGT, 2>(N, kp, nd.offw(l), opt, wave, lane, oc2);
     }
-    if (need_dx) bwd_dx(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
+    if (need_dx) bwd_dx<!__is_same(ND, NetDesc)>(dZ, ldz, N, W, kp, kt0, kt1, acc, wave, lane);
     if (bst && tid == 0 && ll < 2) bst[2 * ll] = clock64();
     if (TRAIN != DW_NONE) {
       ddrl_sync();   // every wave's rows of dZ_l are final and every wave has read W_l

@@ -400,7 +400,11 @@ extern "C" int ddrl_pop_load_flat_dev(ddrl_pop_t *h, int net, const float *d_fla
   if (rc) return rc;
   const uint8_t *dmask;
   if ((rc = upload_mask(h, mask, &dmask))) return rc;
+  // load_flat_kernel walks the InnerProduct layers only: a net with BatchNorm / Scale towers keeps their statistics and
+  // parameters ahead of the InnerProducts in the flat order (pack_flat), which this device-side unpacking does not do
+  if (t->nd.bn_any()) return ddrl_fail(DDRL_EINVAL, "ddrl_pop_load_flat_dev does not serve nets with BatchNorm towers: use ddrl_pop_set_weights");
   HIPCHK(load_flat_launch(&t->nd, net_weights(h, net), d_flat, ld, dmask, h->G, h->stream));
+  if (net == DDRL_NET_ACTOR && h->bn && (rc = refresh_testing(h))) return rc;       // ann_testing follows the actor (DeepQNAg.hpp:469-472)
   DDRL_WAIT(h);
   return DDRL_OK;
 }
@@ -736,7 +740,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   }
   h->P.pair = 0;
   if (h->bn && (rc = refresh_testing(h))) return rc;        // DeepQNAg.hpp:469-472, after the fupd loop
-  if (per_launch > 1) h->multi_pending = true;
+  if (per_launch > 1 || pair || resident || loop) h->multi_pending = true;     // every kernel that can raise the error word (team barriers too)
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
 }
@@ -1185,6 +1189,13 @@ extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
   if (std::string(key) == "force_generic") { h->force_generic = value != 0; return DDRL_OK; }
   if (std::string(key) == "nfac_fuse") { h->nfac_fuse = value != 0; return DDRL_OK; }
   if (std::string(key) == "resident") { h->resident_mode = value != 0; return DDRL_OK; }
+  if (std::string(key) == "debug_raise_update_error") {      // test hook: what an expired hand-off / team-barrier wait leaves behind
+    const int one = value != 0;
+    HIPCHK(hipMemcpyAsync(h->P.upd_error, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->multi_pending = true;
+    return DDRL_OK;
+  }
   if (std::string(key) == "loop") { h->loop_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "pair") { h->pair_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "force_chunked") {     // the gradient + apply kernels of the large-minibatch path on one-tile minibatches

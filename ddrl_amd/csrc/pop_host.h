@@ -205,17 +205,20 @@ static void fill_bn_defaults(const NetDesc &nd, double *flat) {
   }
 }
 
+static inline int ddrl_pop_wait(ddrl_pop *h);      // (below) the stream, and the multi-update launches' error word
+
+// every transfer of state through these helpers waits with ddrl_pop_wait: a launch that skipped updates (an expired
+// hand-off / team-barrier wait) must not be read back as healthy weights, moments or EWC arrays
 static int upload_flat(ddrl_pop *h, const NetDesc &nd, float *dst, const double *flat) {
   std::vector<float> img((size_t)h->G * nd.stride(), 0.f);
   for (int g = 0; g < h->G; ++g) pack_flat(nd, flat + (size_t)g * nd.np, img.data() + (size_t)g * nd.stride());
   HIPCHK(hipMemcpyAsync(dst, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return DDRL_OK;
+  return ddrl_pop_wait(h);
 }
 static int download_flat(ddrl_pop *h, const NetDesc &nd, const float *src, double *flat) {
   std::vector<float> img((size_t)h->G * nd.stride());
   HIPCHK(hipMemcpyAsync(img.data(), src, img.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  { const int rc = ddrl_pop_wait(h); if (rc) return rc; }
   for (int g = 0; g < h->G; ++g) unpack_flat(nd, img.data() + (size_t)g * nd.stride(), flat + (size_t)g * nd.np);
   return DDRL_OK;
 }
@@ -223,8 +226,7 @@ static int download_flat(ddrl_pop *h, const NetDesc &nd, const float *src, doubl
 template <class T>
 static int upload_vec(ddrl_pop *h, T *dst, const std::vector<T> &v) {
   HIPCHK(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return DDRL_OK;
+  return ddrl_pop_wait(h);
 }
 
 static int upload_mask(ddrl_pop *h, const uint8_t *mask, const uint8_t **dmask) {

@@ -172,6 +172,11 @@ class Population:
     def load_previous_run(self, path):
         _l.check(self.L.ddrl_pop_load_previous_run(self.h, str(path).encode()))
 
+    def load_flat_dev(self, d_flat_ptr, ld, mask=None, net=0):
+        """ddrl_pop_load_flat_dev: fp32 rows [G x ld] (ld = 0: one row for every agent) already on the device -> a net's weights"""
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_pop_load_flat_dev(self.h, net, d_flat_ptr, ld, _p(m)))
+
     def set_option(self, key, value):
         _l.check(self.L.ddrl_pop_set_option(self.h, key.encode(), int(value)))
 
@@ -374,6 +379,3 @@ class PolicyPopulation(Population):
                                            output_layer_type, device, init_seed, C.byref(h)))
         self.h, self.G, self.S, self.A = h, n_agents, nb_sensors, nb_motors
 
-    def load_flat_dev(self, d_flat_ptr, ld, mask=None, net=0):
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
-        _l.check(self.L.ddrl_pop_load_flat_dev(self.h, net, d_flat_ptr, ld, _p(m)))

@@ -267,3 +267,24 @@ def test_refusals(kw, msg):
     base.update(kw)
     with pytest.raises(ddrl_amd.DdrlError, match=msg):
         ddrl_amd.DdpgPopulation(ddrl_amd.DdpgConfig(**base), init_seed=0)
+
+
+def test_load_flat_dev_refuses_towers_and_follows_the_actor(ora):
+    """ddrl_pop_load_flat_dev unpacks InnerProduct layers only: a net with towers is refused (its flat order carries the towers'
+    statistics and parameters, which set_weights handles); a tower-free actor beside a critic with towers loads, and
+    ann_testing follows it (DeepQNAg.hpp:469-472)"""
+    import torch
+    from ddrl_amd.lib import DdrlError
+    pop, agents, _ = make_bn_pair(ora, 0, 7, G=2)
+    npa = pop.num_params(0)
+    w = np.random.RandomState(3).normal(0, 0.3, (2, npa)).astype(np.float32)
+    d = torch.from_numpy(w).cuda()
+    pop.load_flat_dev(d.data_ptr(), npa, net=0)
+    assert np.array_equal(pop.weights(0).astype(np.float32), w)
+    s = np.random.RandomState(4).uniform(-1, 1, (2, 18)).astype(np.float32)
+    ref = pop.infer(s)
+    pop.set_weights(0, w.astype(np.float64))                              # the host path refreshes ann_testing too
+    assert np.array_equal(pop.infer(s), ref)
+    with pytest.raises(DdrlError) as e:
+        pop.load_flat_dev(d.data_ptr(), pop.num_params(1), net=1)
+    assert "towers" in str(e.value)

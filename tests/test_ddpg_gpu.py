@@ -545,3 +545,21 @@ def test_best_param_methods_pick_the_reference_snapshot(ora, method):
             assert np.array_equal(ws[g], snaps[chosen[g]][net][g]), (method, net, g, chosen[g])
     if method == 2:
         assert chosen[0] > 0          # agent 0's first score is never beaten: only the age rule can have replaced its snapshot
+
+
+def test_error_word_blocks_every_reader_of_state(ora, tmp_path):
+    """a multi-update launch that skipped updates (an expired hand-off or team-barrier wait raises the launch's error word)
+    must not be read back as healthy state: weights, Adam moments, EWC arrays and run files all fail with DDRL_ESTATE, once;
+    the word is raised here through the test hook "debug_raise_update_error" (what the kernels' bounded waits leave behind)"""
+    from ddrl_amd.lib import DdrlError
+    readers = [lambda p: p.weights(0), lambda p: p.adam(1), lambda p: p.ewc_state(0), lambda p: p.save_run(str(tmp_path / "x.run")),
+               lambda p: p.set_weights(0, np.zeros((2, p.num_params(0))))]
+    pop, _ = make_pair(ora, G=2, B=64, hidden_a=(20,), hidden_q=(50, 7), ewc=10.0, seed=3)
+    pop.update_n(2)
+    pop.sync()
+    for rd in readers:
+        pop.set_option("debug_raise_update_error", 1)
+        with pytest.raises(DdrlError) as e:
+            rd(pop)
+        assert e.value.code == -4 and "skipped" in str(e.value)          # DDRL_ESTATE
+        rd(pop)                                                            # reported once, then the handle answers again

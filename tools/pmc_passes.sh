@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters
-  timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $OUT/$1 -o $1 -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu > $OUT/$1.log 2>&1 || { echo "pass $1 failed"; tail -5 $OUT/$1.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $OUT/$1 -o $1 -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu --no-extra > $OUT/$1.log 2>&1 || { echo "pass $1 failed"; tail -5 $OUT/$1.log; exit 1; }
 }
 run fetch "FETCH_SIZE" && run write "WRITE_SIZE" && \
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" && \

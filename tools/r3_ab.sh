@@ -11,7 +11,7 @@ for args in "${ARGSETS[@]}"; do
   for v in $VARS; do
     so=$PWD/tools/bin/lib_$v.so
     [ "$v" = "tree" ] && so=$PWD/ddrl_amd/libddrl_pop.so
-    DDRL_POP_SO=$so timeout -k 10 240 python3 bench.py --no-cpu $args > $OUT/${v}_$k.json 2> $OUT/${v}_$k.err || { echo "bench $v [$args] failed"; tail -3 $OUT/${v}_$k.err; exit 1; }
+    DDRL_POP_SO=$so timeout -k 10 240 python3 bench.py --no-cpu --no-extra $args > $OUT/${v}_$k.json 2> $OUT/${v}_$k.err || { echo "bench $v [$args] failed"; tail -3 $OUT/${v}_$k.err; exit 1; }
     python3 - "$OUT/${v}_$k.json" "$v" "$args" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -7,7 +7,7 @@ export DDRL_POP_SO=$so
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r03/pmc_$V/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc $CTR --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu > $OUT/log.txt 2>&1 || { echo "pass failed"; tail -5 $OUT/log.txt; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc $CTR --output-format csv -d $OUT -o p -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu --no-extra > $OUT/log.txt 2>&1 || { echo "pass failed"; tail -5 $OUT/log.txt; exit 1; }
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_summary.py $OUT | python3 -c "
 import json,sys

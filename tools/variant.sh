@@ -8,7 +8,7 @@ SRCS="kernels_ddpg.hip kernels_ddpg_pair.hip $*"
 cd "$(dirname "$0")/../ddrl_amd/csrc"
 B=build_v_$NAME
 mkdir -p $B ../../tools/bin
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-result -Wno-pass-failed -DDDRL_NWAVES=4 $EXTRA"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-result -Wno-pass-failed -mllvm -pragma-unroll-threshold=1048576 -DDDRL_NWAVES=4 $EXTRA"
 pids=""
 for s in $SRCS; do /opt/rocm/bin/hipcc $FLAGS -c -x hip $s -o $B/$s.o & pids="$pids $!"; done
 for p in $pids; do wait $p; done
