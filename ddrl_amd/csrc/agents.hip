@@ -32,7 +32,8 @@ struct DevCfg {
   bool on = false, disable_st = false;
   std::vector<long> st_control, ac_control, devpoints;
   bool im = false, reset_learning_algo = false, informed = false;
-  int heuristic = 1;                         // 1: switches at heuristic_devpoints, 2: linear ramps of Bernoulli gates
+  int heuristic = 1;                         // 0: gate weights are parameters, 1: switches at heuristic_devpoints, 2: linear ramps of Bernoulli gates
+  bool st_bern = false, ac_bern = false;     // per-sample Bernoulli(w) gates (the layer's probabilist = 0)
   bool st_scale = false, ac_scale = false;
   std::vector<double> linearcoef;            // heuristic 2 (DODevMLP.hpp:123-130, 444-467)
   int im_smooth = 0, im_window = 0;
@@ -165,15 +166,27 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path, uint64
     const long st_prob = ini.get_long("devnn.st_probabilistic"), ac_prob = ini.get_long("devnn.ac_probabilistic");
     d.disable_st = ini.get("devnn.st_control") == "None";                       // :132-136
     if (!d.disable_st) d.st_control = ini.get_list("devnn.st_control");
-    d.ac_control = ini.get_list("devnn.ac_control");
+    if (ini.get("devnn.ac_control") != "None") d.ac_control = ini.get_list("devnn.ac_control");   // "None" only removes the STATE layer (:132); here it lists nothing (CaffeUtest.cpp:702-708: every action is gated)
     const long heuristic = ini.has("devnn.heuristic") ? ini.get_long("devnn.heuristic") : 0;
-    if (heuristic == 0) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = 0 (gate weights learned by backpropagation) is not supported");
-    if (heuristic != 1 && heuristic != 2) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = %ld unknown", heuristic);
+    // heuristic 0 (the reference's default, :84): the gate weights are ordinary parameters of the nets.  Served: the layer's
+    // forward, the parameter counts and the flat order (ddrl_pop_dev_*); the fork's backward for the gate weights themselves is not
+    // in the tree, so they stay where the caller puts them (they start at 1: the fork's filler is unknown) -- parity unpinned
+    if (heuristic < 0 || heuristic > 2) return ddrl_fail(DDRL_EINVAL, "devnn.heuristic = %ld unknown", heuristic);
+    if (heuristic == 0 && (st_prob < 0 || st_prob > 1 || ac_prob < 0 || ac_prob > 1))
+      return ddrl_fail(DDRL_EINVAL, "devnn.*_probabilistic = 2 / 3 are not documented by the reference (smoke-tested only, CaffeUtest.cpp:1164, 1213)");
+    if (heuristic == 0 && ini.has("devnn.reset_learning_algo") && ini.get_bool("devnn.reset_learning_algo"))
+      return ddrl_fail(DDRL_EINVAL, "when sould I reset, I'm learning alone all my parameters");                        // :202-205
     if (heuristic == 1 && (st_prob != 1 || ac_prob != 1)) return ddrl_fail(DDRL_EINVAL, "heuristic is 1 so probabilistic should be 1");   // :90-93
     if (heuristic == 2 && (st_prob != 0 || ac_prob != 0)) return ddrl_fail(DDRL_EINVAL, "heuristic is 2 so probabilistic should be 0");   // :94-97
     if ((ac_scale && ac_prob != 0) || (st_scale && st_prob != 0))
       return ddrl_fail(DDRL_EINVAL, "if not probabilistic then why scaling? of how much?");                              // :192-195
     d.heuristic = (int)heuristic; d.st_scale = st_scale; d.ac_scale = ac_scale;
+    d.st_bern = heuristic == 2 || (heuristic == 0 && st_prob == 0);
+    d.ac_bern = heuristic == 2 || (heuristic == 0 && ac_prob == 0);
+    if (heuristic == 0) {                       // an empty list gates every dimension (CaffeUtest.cpp:629-636)
+      if (!d.disable_st && d.st_control.empty()) for (int i = 0; i < h->S; ++i) d.st_control.push_back(i);
+      if (d.ac_control.empty()) for (int i = 0; i < h->A; ++i) d.ac_control.push_back(i);
+    }
     if (ini.has("devnn.intrasec_motivation")) d.im = ini.get_bool("devnn.intrasec_motivation");
     if (d.im && heuristic != 1)
       return ddrl_fail(DDRL_EINVAL, "intrasec motiv works only with determinist activation and heuristic = 1");          // :104-107
@@ -183,7 +196,7 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path, uint64
       if (d.devpoints.size() != d.st_control.size() + d.ac_control.size())                 // :119-120
         return ddrl_fail(DDRL_EINVAL, "heuristic_devpoints has %zu entries for %zu + %zu controlled dimensions", d.devpoints.size(),
                          d.st_control.size(), d.ac_control.size());
-    } else {
+    } else if (heuristic == 2) {
       d.linearcoef = colon_doubles(ini.get("devnn.heuristic_linearcoef"));
       if (d.linearcoef.size() < d.st_control.size() + d.ac_control.size())                 // :126-127
         return ddrl_fail(DDRL_EINVAL, "heuristic_linearcoef has %zu entries for %zu + %zu controlled dimensions", d.linearcoef.size(),
@@ -201,7 +214,7 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path, uint64
     return ddrl_fail(DDRL_EIO, "%s: %s", ini_path, e.what());
   }
   if (d.im && (d.im_smooth < 1 || d.im_window < 0)) return ddrl_fail(DDRL_EINVAL, "devnn.im_smooth < 1 or im_window < 0");
-  if (d.st_control.empty() && !d.disable_st) return ddrl_fail(DDRL_EINVAL, "devnn.st_control: list the gated dimensions or None");
+  if (d.st_control.empty() && !d.disable_st) return ddrl_fail(DDRL_EINVAL, "devnn.st_control: list the gated dimensions or None");   // (heuristic 0 filled an empty list above)
   for (long c : d.st_control) if (c < 0 || c >= h->S) return ddrl_fail(DDRL_EINVAL, "devnn.st_control %ld outside 0..%d", c, h->S - 1);
   for (long c : d.ac_control) if (c < 0 || c >= h->A) return ddrl_fail(DDRL_EINVAL, "devnn.ac_control %ld outside 0..%d", c, h->A - 1);
   if (d.heuristic == 2 && d.informed) return ddrl_fail(DDRL_EINVAL, "informed_sensorimotor_space is not implemented with proba action");   // :161-169
@@ -209,13 +222,21 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path, uint64
   if (d.heuristic == 2 && h->algo == 3) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the TD3 update");
   if (h->algo == 1 && d.reset_learning_algo) return ddrl_fail(DDRL_EINVAL, "NFAC cannot reset anything with DODevMLP");   // OfflineCaclaAg.hpp:199-203
   if (h->algo == 2) return ddrl_fail(DDRL_EINVAL, "the developmental schedule is not supported for CMA-ES agents");
-  if (d.heuristic == 2) {
-    int rc = ddrl_pop_set_gate_mode(h->pop, 1, d.st_scale ? 1 : 0, 1, d.ac_scale ? 1 : 0, (uint32_t)(seed * 2246822519ull + 374761393u));
+  if (d.st_bern || d.ac_bern) {
+    if (h->algo == 3) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the TD3 update");
+    int rc = ddrl_pop_set_gate_mode(h->pop, d.st_bern ? 1 : 0, d.st_scale ? 1 : 0, d.ac_bern ? 1 : 0, d.ac_scale ? 1 : 0,
+                                    (uint32_t)(seed * 2246822519ull + 374761393u));
+    if (rc) return rc;
+  }
+  {
+    std::vector<int> st(d.st_control.begin(), d.st_control.end()), ac(d.ac_control.begin(), d.ac_control.end());
+    int rc = ddrl_pop_set_gate_layout(h->pop, st.data(), d.disable_st ? -1 : (int)st.size(), ac.data(), (int)ac.size(), d.heuristic == 0);
     if (rc) return rc;
   }
   d.on = true;
   h->devst.resize(h->G);
-  for (auto &st : h->devst) { st.st_w.assign(d.st_control.size(), 0.); st.ac_w.assign(d.ac_control.size(), 0.); }
+  const double w0 = d.heuristic == 0 ? 1. : 0.;           // :358-374 zeroes the blobs under heuristic != 0 only
+  for (auto &st : h->devst) { st.st_w.assign(d.st_control.size(), w0); st.ac_w.assign(d.ac_control.size(), w0); }
   return DDRL_OK;
 }
 
@@ -226,11 +247,10 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path, uint64
 static int push_gates(ddrl_agents *h) {
   const DevCfg &d = h->dev;
   std::vector<double> sg((size_t)h->G * h->S, 1.), ag((size_t)h->G * h->A, 1.);
-  const bool prob = d.heuristic == 2;
-  auto gate = [prob](double w) { return prob ? std::min(1., std::max(0., w)) : (w < 0.5 ? 0. : 1.); };
+  auto gate = [](bool prob, double w) { return prob ? std::min(1., std::max(0., w)) : (w < 0.5 ? 0. : 1.); };
   for (int g = 0; g < h->G; ++g) {
-    for (size_t i = 0; i < d.st_control.size(); ++i) sg[(size_t)g * h->S + d.st_control[i]] = gate(h->devst[g].st_w[i]);
-    for (size_t i = 0; i < d.ac_control.size(); ++i) ag[(size_t)g * h->A + d.ac_control[i]] = gate(h->devst[g].ac_w[i]);
+    for (size_t i = 0; i < d.st_control.size(); ++i) sg[(size_t)g * h->S + d.st_control[i]] = gate(d.st_bern, h->devst[g].st_w[i]);
+    for (size_t i = 0; i < d.ac_control.size(); ++i) ag[(size_t)g * h->A + d.ac_control[i]] = gate(d.ac_bern, h->devst[g].ac_w[i]);
   }
   return ddrl_pop_set_gates(h->pop, sg.data(), ag.data());
 }
@@ -256,6 +276,7 @@ static bool still_something(const DevCfg &d, const DevState &st) {
 // DODevMLP::inform (:566-574) for one agent: returns changed; *setup = ewc_setup() was called
 static bool dev_inform(const DevCfg &d, DevState &st, int episode, double score, bool *setup) {
   *setup = false;
+  if (d.heuristic == 0) return false;                                  // nothing is scheduled: the gate weights are parameters
   if (d.heuristic == 2) {                                              // develop (:444-467): every episode, ewc_setup() first
     for (size_t i = 0; i < d.st_control.size(); ++i) st.st_w[i] = d.linearcoef[i] >= 1. ? 1. : (double)episode * d.linearcoef[i];
     for (size_t i = 0; i < d.ac_control.size(); ++i) {
@@ -823,7 +844,7 @@ static int agents_run_file(ddrl_agents *h, const char *path, bool save) {
   Ckpt c;
   if ((rc = c.open(path, save)) || (rc = agents_checkpoint(h, c))) return rc;
   if ((rc = c.finish())) return rc;
-  if (!save && h->dev.on) return push_gates(h);          // the device gates follow the restored schedule state
+  if (!save && h->dev.on && h->dev.heuristic != 0) return push_gates(h);          // the device gates follow the restored schedule state (heuristic 0: the population's file holds them)
   return DDRL_OK;
 }
 extern "C" int ddrl_agents_save_run(ddrl_agents_t *h, const char *path) { return agents_run_file(h, path, true); }

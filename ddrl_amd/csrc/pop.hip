@@ -876,7 +876,7 @@ extern "C" int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   int rc = set_device(h);
   if (rc) return rc;
-  if (!state_gate && !action_gate) { h->gates_on = false; return DDRL_OK; }
+  if (!state_gate && !action_gate) { h->gates_on = false; h->gate_w_s.clear(); h->gate_w_a.clear(); return DDRL_OK; }
   if (h->bn) return ddrl_fail(DDRL_EINVAL, "developmental gates on BatchNorm nets are not supported");
   const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
   if (!h->d_sgate) {
@@ -889,6 +889,7 @@ extern "C" int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const
   if ((rc = upload_vec(h, h->d_sgate, sg))) return rc;
   if ((rc = upload_vec(h, h->d_agate, ag))) return rc;
   h->gates_on = true;
+  h->gate_w_s.assign(sg.begin(), sg.end()); h->gate_w_a.assign(ag.begin(), ag.end());   // the view's weights, until dev_set_weights says otherwise
   return DDRL_OK;
 }
 
@@ -919,6 +920,92 @@ extern "C" int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_sc
   h->gm.ac_bern = ac_bernoulli ? 1 : 0; h->gm.ac_scale = ac_scale ? 1 : 0;
   h->gm.seed = seed; h->gm.draw = 0;
   h->P.gm = h->gm;
+  return DDRL_OK;
+}
+
+// ---- DODevMLP's flat parameter view (gate blobs included) ----
+extern "C" int ddrl_pop_set_gate_layout(ddrl_pop_t *h, const int *st_control, int n_st, const int *ac_control, int n_ac, int learnable) {
+  if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
+  const int S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
+  if ((n_st > 0 && !st_control) || (n_ac > 0 && !ac_control) || n_st > S || n_ac > A) return ddrl_fail(DDRL_EINVAL, "bad control list");
+  std::vector<int> st, ac;
+  if (n_st == 0) for (int i = 0; i < S; ++i) st.push_back(i);                    // an empty list gates every dimension (CaffeUtest.cpp:629-636)
+  for (int i = 0; i < n_st; ++i) { if (st_control[i] < 0 || st_control[i] >= S) return ddrl_fail(DDRL_EINVAL, "st_control %d outside 0..%d", st_control[i], S - 1); st.push_back(st_control[i]); }
+  if (n_ac == 0) for (int i = 0; i < A; ++i) ac.push_back(i);
+  for (int i = 0; i < n_ac; ++i) { if (ac_control[i] < 0 || ac_control[i] >= A) return ddrl_fail(DDRL_EINVAL, "ac_control %d outside 0..%d", ac_control[i], A - 1); ac.push_back(ac_control[i]); }
+  h->st_control = st; h->ac_control = ac;
+  h->st_layer = n_st >= 0; h->ac_layer = n_ac >= 0;
+  h->gates_learnable = learnable != 0;
+  if (!h->gates_on && (h->st_layer || h->ac_layer)) {
+    std::vector<double> one((size_t)h->G * (size_t)std::max(S, A), 1.);
+    return ddrl_pop_set_gates(h, one.data(), one.data());
+  }
+  return DDRL_OK;
+}
+
+// gate weights in the view: which, and where.  Actor: [state gate][InnerProducts][action gate]; critic: [action gate][state gate][InnerProducts]
+static void dev_view(const ddrl_pop *h, int net, int ignore_null_lr, bool &actor, size_t &ns, size_t &na) {
+  actor = net == DDRL_NET_ACTOR || net == DDRL_NET_ACTOR_TARGET;
+  const bool counted = h->gates_learnable || !ignore_null_lr;
+  ns = counted && h->st_layer ? h->st_control.size() : 0;
+  na = counted && h->ac_layer ? h->ac_control.size() : 0;
+}
+
+extern "C" int ddrl_pop_dev_num_params(ddrl_pop_t *h, int net, int ignore_null_lr, int *n) {
+  if (!h || !n || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  bool actor; size_t ns, na;
+  dev_view(h, net, ignore_null_lr, actor, ns, na);
+  *n = train_net(h, net)->nd.np + (int)(ns + na);
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_dev_get_weights(ddrl_pop_t *h, int net, int ignore_null_lr, double *flat) {
+  if (!h || !flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  bool actor; size_t ns, na;
+  dev_view(h, net, ignore_null_lr, actor, ns, na);
+  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors, np = train_net(h, net)->nd.np, n = np + ns + na;
+  std::vector<double> w(G * np), sg(h->gate_w_s), ag(h->gate_w_a);
+  sg.resize(G * S, 1.); ag.resize(G * A, 1.);
+  int rc = ddrl_pop_get_weights(h, net, w.data());
+  if (rc) return rc;
+  for (size_t g = 0; g < G; ++g) {
+    double *o = flat + g * n;
+    size_t k = 0;
+    if (!actor) for (size_t i = 0; i < na; ++i) o[k++] = ag[g * A + h->ac_control[i]];
+    for (size_t i = 0; i < ns; ++i) o[k++] = sg[g * S + h->st_control[i]];
+    for (size_t i = 0; i < np; ++i) o[k++] = w[g * np + i];
+    if (actor) for (size_t i = 0; i < na; ++i) o[k++] = ag[g * A + h->ac_control[i]];
+  }
+  return DDRL_OK;
+}
+
+extern "C" int ddrl_pop_dev_set_weights(ddrl_pop_t *h, int net, int ignore_null_lr, const double *flat) {
+  if (!h || !flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
+  bool actor; size_t ns, na;
+  dev_view(h, net, ignore_null_lr, actor, ns, na);
+  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors, np = train_net(h, net)->nd.np, n = np + ns + na;
+  std::vector<double> w(G * np), sg(h->gate_w_s), ag(h->gate_w_a);
+  sg.resize(G * S, 1.); ag.resize(G * A, 1.);
+  int rc;
+  for (size_t g = 0; g < G; ++g) {
+    const double *o = flat + g * n;
+    size_t k = 0;
+    if (!actor) for (size_t i = 0; i < na; ++i) ag[g * A + h->ac_control[i]] = o[k++];
+    for (size_t i = 0; i < ns; ++i) sg[g * S + h->st_control[i]] = o[k++];
+    for (size_t i = 0; i < np; ++i) w[g * np + i] = o[k++];
+    if (actor) for (size_t i = 0; i < na; ++i) ag[g * A + h->ac_control[i]] = o[k++];
+  }
+  if ((rc = ddrl_pop_set_weights(h, net, w.data()))) return rc;
+  if (!(ns + na)) return DDRL_OK;
+  // the layer's forward from its weight (DevelopmentalLayer): probabilist = 1 passes a dimension whose weight is
+  // at least 0.5 and zeroes the others; probabilist = 0 draws Bernoulli(w) per sample, so the device holds w itself (within [0, 1])
+  std::vector<double> fs(sg), fa(ag);
+  for (size_t g = 0; g < G; ++g) {
+    for (int c : h->st_control) { double &v = fs[g * S + c]; v = h->gm.st_bern ? std::min(1., std::max(0., v)) : (v < 0.5 ? 0. : 1.); }
+    for (int c : h->ac_control) { double &v = fa[g * A + c]; v = h->gm.ac_bern ? std::min(1., std::max(0., v)) : (v < 0.5 ? 0. : 1.); }
+  }
+  if ((rc = ddrl_pop_set_gates(h, fs.data(), fa.data()))) return rc;
+  h->gate_w_s = sg; h->gate_w_a = ag;
   return DDRL_OK;
 }
 
@@ -1108,7 +1195,14 @@ int ddrl_pop_checkpoint(ddrl_pop *h, Ckpt &c) {
     if ((rc = c.dev("gates.state", h->d_sgate, G * h->cfg.nb_sensors * sizeof(float))) ||
         (rc = c.dev("gates.action", h->d_agate, G * h->cfg.nb_motors * sizeof(float)))) return rc;
   }
-  if (!c.writing) h->gates_on = gates != 0;
+  if (!c.writing) {
+    h->gates_on = gates != 0;
+    h->gate_w_s.clear(); h->gate_w_a.clear();
+    if (gates) {          // the flat view's gate weights are not in the file: they restart from the factors the device holds
+      h->gate_w_s.resize(G * h->cfg.nb_sensors); h->gate_w_a.resize(G * h->cfg.nb_motors);
+      if ((rc = ddrl_pop_get_gates(h, h->gate_w_s.data(), h->gate_w_a.data()))) return rc;
+    }
+  }
   {
     int g6[6] = {h->gm.st_bern, h->gm.st_scale, h->gm.ac_bern, h->gm.ac_scale, (int)h->gm.seed, (int)h->gm.draw};
     for (int i = 0; i < 6; ++i) {

@@ -90,6 +90,11 @@ struct ddrl_pop {
   double beta1 = 0., beta2 = 0.999;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
+  // DODevMLP's gate blobs as part of the flat parameter view (ddrl_pop_set_gate_layout): controlled dimensions per gate
+  // (-1 entries never; n < 0: no such layer), and whether the weights are learnable_params with lr_mult 1 (heuristic 0)
+  std::vector<double> gate_w_s, gate_w_a;   // the gate WEIGHTS [G x S], [G x A] the flat view shows (the device holds the factors made of them)
+  std::vector<int> st_control, ac_control;
+  bool st_layer = false, ac_layer = false, gates_learnable = false;
   int loop_mode = 1;          // multi-update launches keep an agent's updates in one workgroup (ddpg_update_loop_kernel): 0 never, 1 where it pays (mid nets), 2 whenever the shapes are compile-time ones
 };
 

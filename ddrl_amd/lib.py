@@ -136,6 +136,10 @@ SYMBOLS = [
     ("ddrl_agents_cmaes_state", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("ddrl_policy_create", _i, [_i, _i, _i, _vp, _i, _i, _i, _i, C.c_uint64, C.POINTER(_vp)]),
     ("ddrl_pop_load_flat_dev", _i, [_vp, _i, _vp, _i, _vp]),
+    ("ddrl_pop_set_gate_layout", _i, [_vp, _vp, _i, _vp, _i, _i]),
+    ("ddrl_pop_dev_num_params", _i, [_vp, _i, _i, C.POINTER(C.c_int)]),
+    ("ddrl_pop_dev_get_weights", _i, [_vp, _i, _i, _vp]),
+    ("ddrl_pop_dev_set_weights", _i, [_vp, _i, _i, _vp]),
     ("ddrl_agents_destroy", _i, [_vp]),
     ("ddrl_agents_population", _vp, [_vp]),
     ("ddrl_agents_start_episode", _i, [_vp, _vp, _vp, _vp]),

@@ -172,6 +172,32 @@ class Population:
     def load_previous_run(self, path):
         _l.check(self.L.ddrl_pop_load_previous_run(self.h, str(path).encode()))
 
+    # DODevMLP's flat parameter view, gate blobs included (ddrl_pop_set_gate_layout and friends)
+    def set_gate_layout(self, st_control, ac_control, learnable):
+        """st_control / ac_control: list of controlled dimensions, [] = every dimension, None = no such gate layer;
+        learnable: heuristic 0 (gate weights are lr_mult-1 parameters)"""
+        def arg(c):
+            if c is None:
+                return None, -1
+            a = np.ascontiguousarray(c, np.int32)
+            return a, int(a.size)
+        s, ns = arg(st_control); a, na = arg(ac_control)
+        _l.check(self.L.ddrl_pop_set_gate_layout(self.h, _p(s) if ns > 0 else None, ns, _p(a) if na > 0 else None, na, int(learnable)))
+
+    def dev_num_params(self, net, ignore_null_lr=True):
+        n = C.c_int()
+        _l.check(self.L.ddrl_pop_dev_num_params(self.h, net, int(ignore_null_lr), C.byref(n)))
+        return n.value
+
+    def dev_weights(self, net, ignore_null_lr=True):
+        out = np.empty((self.G, self.dev_num_params(net, ignore_null_lr)), np.float64)
+        _l.check(self.L.ddrl_pop_dev_get_weights(self.h, net, int(ignore_null_lr), _p(out)))
+        return out
+
+    def set_dev_weights(self, net, flat, ignore_null_lr=True):
+        f = np.ascontiguousarray(flat, np.float64).reshape(self.G, self.dev_num_params(net, ignore_null_lr))
+        _l.check(self.L.ddrl_pop_dev_set_weights(self.h, net, int(ignore_null_lr), _p(f)))
+
     def load_flat_dev(self, d_flat_ptr, ld, mask=None, net=0):
         """ddrl_pop_load_flat_dev: fp32 rows [G x ld] (ld = 0: one row for every agent) already on the device -> a net's weights"""
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)

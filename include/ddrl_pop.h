@@ -201,6 +201,25 @@ int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate);
  * generator keyed on seed / pass / agent / layer instance / row / dimension: the fork's generator is unknown, only the
  * pass rates are pinned).  Served by the one-tile DDPG update, NFAC, infer and forward_batch; DDRL_EINVAL elsewhere. */
 int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed);
+/* DODevMLP's view of a net's parameters: after DODevMLP::exploit (DODevMLP.hpp:216-401) the gate weights are blobs of the
+ * net, so number_of_parameters / copyWeightsTo / copyWeightsFrom (MLP.hpp:610-676) count and carry them:
+ *   - an actor lists the state-gate weights first and the action-gate weights last (CaffeUtest.cpp:652-656, 964-965), a
+ *     critic the action-gate weights, then the state-gate weights, then its InnerProducts (learnable_params()[1] is the
+ *     state gate, :964; its copy of the flat vector holds the state gate at [len(ac_control) ..), :1001-1003);
+ *   - a gate blob has one weight per controlled dimension, or per dimension when the control list is empty (+S / +A
+ *     parameters, :629-636, :702-708), none when the list is "None" (n = -1 here);
+ *   - heuristic 0 (the reference's default, DODevMLP.hpp:84: `learnable` != 0) leaves the gate weights lr_mult 1, so they
+ *     are part of the view with ignore_null_lr as well; heuristic 1 / 2 freeze them (lr_mult 0, :381-385, :395-399): they
+ *     are counted only with ignore_null_lr = 0 (CaffeUtest.cpp:1313-1314).
+ * ddrl_pop_set_gate_layout records the control lists (an agent's nets share ONE set of gate weights, as the reference's
+ * actor and critic share the blobs, :343-355; the targets here share them too) and, when no gates are set yet, installs
+ * all-ones gates.  What heuristic 0 does NOT do here: the fork's Developmental layer backward for its own weights is not
+ * in the tree, so the update kernels leave gate weights where the caller put them (parity unpinned; the forward, the
+ * counts and the order are the reference's). */
+int ddrl_pop_set_gate_layout(ddrl_pop_t *h, const int *st_control, int n_st, const int *ac_control, int n_ac, int learnable);
+int ddrl_pop_dev_num_params(ddrl_pop_t *h, int net, int ignore_null_lr, int *n);
+int ddrl_pop_dev_get_weights(ddrl_pop_t *h, int net, int ignore_null_lr, double *flat);        /* [G x n] */
+int ddrl_pop_dev_set_weights(ddrl_pop_t *h, int net, int ignore_null_lr, const double *flat);  /* [G x n] */
 
 /* EWC life-cycle (DODevMLP.hpp:604-758), per agent with mask[g] != 0 */
 int ddrl_pop_update_best_param(ddrl_pop_t *h, const double *score /* [G] */, const uint8_t *mask);

@@ -2,7 +2,8 @@
 heuristic_devpoints switches, the intrinsic-motivation variant, reset_learning_algo, ewc_setup at a
 switch, neutral_action (DODevMLP.hpp:403-574, 764-775; DeepQNAg.hpp:250-272).  The schedule is host
 logic; expectations are written out by hand for the devpoints case and restated from the reference's
-developIM for the other.  No reference test drives inform(): parity unpinned."""
+developIM for the other.  The one reference test that drives inform() (CaffeUtest.cpp:1257-1341, devpoints 0,0,30,30) is restated
+in tests/test_dev_layer_fixtures_gpu.py; the schedules beyond it (later devpoints, developIM, resets) are parity unpinned."""
 import os
 
 import numpy as np
@@ -217,7 +218,7 @@ def write_nfac(tmp_path):
 
 
 @pytest.mark.parametrize("kw,msg", [
-    (dict(heur=0), "learned"), (dict(heur=2), "probabilistic"), (dict(dp="1:2"), "heuristic_devpoints"),
+    (dict(heur=0), "learning alone"), (dict(heur=0, reset="false"), None), (dict(heur=2), "probabilistic"), (dict(dp="1:2"), "heuristic_devpoints"),
     (dict(st="1:9"), "st_control"), (dict(im="true", heur=1, dp="0:1:2", reset="true"), None)])
 def test_config_checks(tmp_path, kw, msg):
     import ddrl_amd
