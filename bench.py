@@ -105,6 +105,7 @@ def cpu_baseline(S, A, B, ha, hq, ewc, seconds, threads, replay):
 PAIR_MODE = 0
 RESIDENT = 0
 LOOP = 1
+W8 = 0
 KERNEL_SOURCES = ("kernels_ddpg.hip", "kernels_ddpg_pair.hip", "ddpg_update_body.h", "ddpg_device.h", "net_device.h", "mlp_device.h", "pop_internal.h")
 
 
@@ -204,6 +205,7 @@ def build_population(G, rank, first_agent, S, A, B, ha, hq, ewc, replay, local_r
     pop.set_option("pair", PAIR_MODE)
     pop.set_option("resident", RESIDENT)
     pop.set_option("loop", LOOP)
+    pop.set_option("w8", W8)
     # per-agent hyper-parameters and replay depend on the agent's id in the whole sweep, not on the sharding
     ids = first_agent + np.arange(G)
     hyp = np.array([np.random.RandomState(3000 + i).uniform(size=3) for i in ids]).reshape(G, 3)
@@ -471,16 +473,18 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the secondary configurations (`extra` in the JSON line)")
     ap.add_argument("--pair", type=int, default=0, help="0: one agent per workgroup always (default); 1: agent pairs for launches of >= 4 updates; 2: pairs whenever they fit")
     ap.add_argument("--loop", type=int, default=1, help="multi-update launches keep an agent's updates in one workgroup (ddpg_update_loop_kernel): 1 where it pays (mid nets), 2 always, 0: one workgroup per (update, agent)")
+    ap.add_argument("--w8", type=int, default=0, help="eight waves per agent (kernels_ddpg_w8.hip, opt-in: measured slower): 0 never (default), 1 for populations of up to 256 agents per GPU, 2 always")
     ap.add_argument("--resident", type=int, default=0, help="1: small nets keep an agent's state in LDS over a multi-update launch")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / clock reduction only (gloo, no GPU, no library)")
     ap.add_argument("--updates-per-launch", type=int, default=8,
                     help="consecutive updates per agent fused into one launch (ddrl_pop_ddpg_update_n): the reference's "
                          "fupd loop, 1 + force_more_update = 8 in its ddpg.ini; bit-identical to separate launches")
     args = ap.parse_args()
-    global PAIR_MODE, RESIDENT, LOOP
+    global PAIR_MODE, RESIDENT, LOOP, W8
     PAIR_MODE = args.pair
     RESIDENT = args.resident
     LOOP = args.loop
+    W8 = args.w8
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)        # nothing above has touched the GPU (or imported torch)
@@ -591,6 +595,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ("ddpg_update_pair_kernel" if (PAIR_MODE == 2 or (upl >= 4 and PAIR_MODE and args.size == "mid" and G > 512)) else
+                                "ddpg_update_loop8_kernel" if (args.size == "mid" and (W8 == 2 or (W8 == 1 and LOOP > 0 and G <= 256)) and PAIR_MODE != 2) else
                                 "ddpg_update_loop_kernel" if (upl >= 2 and ((LOOP == 1 and args.size == "mid") or LOOP == 2)) else "ddpg_update_kernel") if max(ha + hq) <= 128 else "wide_* layer kernels, optimiser inside the dW kernels (one update = 45 launches)",
                      "kernel_avg_ms": kavg * 1e3, "launches": launches,
                      "updates_per_launch": upl_eff, "algorithmic_bytes_per_launch": byts * G * upl_eff,

@@ -109,7 +109,7 @@ __device__ __forceinline__ void ddpg_q0(const DdpgParams &P, float *lds, int age
   // the first weight fragments of the actor-target pass travel while the minibatch is gathered
   FwdCarry cy;
   const FwdNext no_next = {nullptr, nullptr, 4, 1};
-  if (!__is_same(NA, NetDesc)) fwd_request(fwd_first(na, V.w_at), lane, cy);
+  if (!__is_same(NA, NetDesc)) fwd_request(fwd_first(na, V.w_at), lane, cy, wave);
 #ifdef DDRL_EXP_TOUCHW   // measured: the passes 2 k cycles shorter each, this quarter 21 k longer (the touches queue ahead of the gather)
   l2_touch_block(V.w_at, na.stride(), M.dump, tid);
   l2_touch_block(V.w_qt, nq.stride(), M.dump, tid);
@@ -192,7 +192,7 @@ __device__ __forceinline__ void ddpg_q1(const DdpgParams &P, float *lds, int age
 // (252 of an update's 2 912 MFMAs per wave, one more read of the actor's weights, 25-30 k of its ~500 k cycles).
 // Exact: the second forward pass recomputed the same values from the same inputs.
 template <class NA> struct KeepHidden {
-  static constexpr int per(int l) { return (4 * NA::ld(l + 1) + 63) / 64; }          // float4 per lane of hidden tile l
+  static constexpr int per(int l) { return ddrl_slots((4 * NA::ld(l + 1) + 63) / 64); }   // float4 per lane of hidden tile l (two waves per row tile: every other one)
   static constexpr int before(int l) { int t = 0; for (int i = 0; i < l; ++i) t += per(i); return t; }
   static constexpr int total = before(NA::L() - 1);
   static constexpr bool value = total >= 1 && total <= 16;
@@ -205,10 +205,10 @@ __device__ __forceinline__ void keep_hidden(float *hbase, int hstride, int wave,
 #pragma unroll
     for (int l = 0; l < NA::L() - 1; ++l) {
       const int ld = NA::ld(l + 1), nf4 = 4 * ld;                  // float4s in this wave's 16 rows
-      float *base = hbase + l * hstride + 16 * wave * ld;
+      float *base = hbase + l * hstride + 16 * ddrl_rt(wave) * ld;
 #pragma unroll
       for (int j = 0; j < KeepHidden<NA>::per(l); ++j) {
-        const int f = lane + 64 * j;
+        const int f = lane + 64 * (ddrl_part(wave) + DDRL_PARTS * j);
         if (f < nf4) {
           if (SAVE) keep[KeepHidden<NA>::before(l) + j] = *(const f32x4 *)(base + 4 * f);
           else *(f32x4 *)(base + 4 * f) = keep[KeepHidden<NA>::before(l) + j];

@@ -7,6 +7,7 @@ STUB_ERR(ddpg_update_big_launch)
 STUB_ERR(ddpg_update_wide_launch)
 STUB_ERR(ddpg_update_pair_launch)
 STUB_ERR(ddpg_update_resident_launch)
+STUB_ERR(ddpg_update_loop8_launch)
 STUB_ERR(td3_update_launch)
 STUB_ERR(td3_update_big_launch)
 STUB_ERR(td3_update_wide_launch)
@@ -16,6 +17,7 @@ STUB_ERR(net_forward_bn_launch)
 STUB_ERR(net_forward_launch)
 STUB_ERR(net_forward_wide_launch)
 STUB_ZERO(ddpg_update_pair_ok)
+STUB_ZERO(ddpg_update_loop8_ok)
 STUB_ZERO(ddpg_update_pair_pays)
 STUB_ZERO(ddpg_update_resident_ok)
 STUB_ZERO(ddpg_update_bn_lds_bytes)

@@ -52,6 +52,22 @@ __device__ __forceinline__ void ddrl_sync() {
 __device__ __forceinline__ void ddrl_sync() { __syncthreads(); }
 #endif
 
+// ROW TILES AND COLUMN PARTS.  A batch tile has four 16-row tiles.  With four waves per workgroup (the default) wave w owns
+// row tile w and every column tile of it.  A translation unit built with DDRL_NWAVES = 8 (kernels_ddpg_w8.hip: one
+// 512-thread workgroup per agent, two waves per SIMD, for populations that do not fill the CUs with 256-thread
+// workgroups) gives each row tile to TWO waves, w and w + 4: the compile-time-shape passes deal a layer's column tiles to
+// them alternately (`part` 0 takes tiles 0, 2, 4 ..., part 1 tiles 1, 3, 5 ...) and close every layer with a workgroup
+// barrier instead of the wave's own LDS fence.  Both parts walk the same number of tile slots; a slot beyond the layer's
+// last tile repeats that tile (clamped loads, products on valid data) and stores nothing.
+#define DDRL_PARTS (DDRL_NWAVES / 4)
+static_assert(DDRL_NWAVES % 4 == 0 && DDRL_MB == 64 && DDRL_PARTS >= 1 && DDRL_PARTS <= 2, "row tiles: four per batch tile, one or two waves each");
+__device__ __forceinline__ int ddrl_rt(int wave) { return DDRL_PARTS == 1 ? wave : (wave & 3); }
+__device__ __forceinline__ int ddrl_part(int wave) { return DDRL_PARTS == 1 ? 0 : (wave >> 2); }
+static __host__ __device__ constexpr int ddrl_slots(int tiles) { return (tiles + DDRL_PARTS - 1) / DDRL_PARTS; }   // tile slots of one part
+#ifdef DDRL_TEAMS
+static_assert(DDRL_NWAVES == 4, "two-team workgroups: the team barrier counts four waves");
+#endif
+
 #ifndef DDRL_F64_DEBUG
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -81,6 +97,39 @@ __device__ __forceinline__ const float *opaque(const float *p) {
   int z = 0;
   asm volatile("" : "+s"(z));      // an offset of 0 the optimiser cannot see; the address space of p is kept
   return p + z;
+}
+
+// a uniform GLOBAL pointer whose value (constant offsets included) the optimiser cannot see into: it stays one scalar register
+// pair instead of being re-associated into the lanes' side of an address
+// (DDRL_STATE_IN_LDS: a translation unit whose kernels may hand these blocks weights that live in LDS -- the resident kernel of
+// kernels_ddpg_pair.hip -- must not name an address space: there the pointer keeps its provenance and the older offset trick)
+__device__ __forceinline__ const float *opaque_base(const float *p) {
+#if defined(DDRL_F64_DEBUG)
+  return p;
+#elif defined(DDRL_STATE_IN_LDS)
+  return opaque(p);
+#else
+  typedef const float __attribute__((address_space(1))) *gptr;
+  gptr q = (gptr)p;
+  asm volatile("" : "+s"(q));
+  return (const float *)q;
+#endif
+}
+// A global access as UNIFORM base + 32-bit per-lane byte offset: the form the hardware takes directly (scalar base register pair +
+// vector offset), so the lane's 64-bit address is never built on the vector ALU (a v_lshl_add_u64 per access otherwise -- the
+// fp32 MFMAs run on the same ALU, every vector instruction saved is MFMA time).  ubase must be wave-uniform.
+// The hardware form is only selected when the offset's zero-extension is visible in the basic block of the access: callers pass
+// offsets through fresh_lane() at the top of the block that uses them (no instruction; it only keeps the value from being widened
+// once, far away, into a 64-bit register pair that every access then adds to its base on the vector ALU).
+__device__ __forceinline__ unsigned fresh_lane(unsigned lane_floats) {
+  asm volatile("" : "+v"(lane_floats));
+  return lane_floats;
+}
+__device__ __forceinline__ const float *lane_at(const float *ubase, unsigned lane_floats) {
+  return (const float *)((const char *)ubase + lane_floats * 4u);
+}
+__device__ __forceinline__ float *lane_at(float *ubase, unsigned lane_floats) {
+  return (float *)((char *)ubase + lane_floats * 4u);
 }
 
 // Cache warming without registers (EXPERIMENT switches DDRL_EXP_TOUCHW / DDRL_EXP_TOUCHSTATE only, never defined in the
@@ -159,7 +208,6 @@ __device__ __forceinline__ void load_bfrag(const float *__restrict__ W, const fl
   }
 }
 
-static_assert(DDRL_NWAVES * 16 == DDRL_MB, "row-parallel passes: one 16-row tile per wave");
 
 // The activation fragments of this wave's 16 rows for a whole layer input: row 16w + c, columns
 // kc*16 + 4g .. + 3 for every 16-deep k-chunk.  Columns >= kp are zeroed HERE (one LDS-side select per
@@ -170,7 +218,7 @@ struct WCol { float v[DDRL_MAXKC][4]; float t[3]; };     // the weight fragments
 
 __device__ __forceinline__ void load_afrag(const float *__restrict__ Xs, int ldx, int kp, int wave, int lane, AFrag &a) {
   const int g = lane >> 4, c = lane & 15;
-  const float *row = Xs + (16 * wave + c) * ldx;
+  const float *row = Xs + (16 * ddrl_rt(wave) + c) * ldx;
 #pragma unroll
   for (int kc = 0; kc < DDRL_MAXKC; ++kc)
     if (kc * 16 < kp) {
@@ -211,7 +259,7 @@ __host__ __device__ constexpr int st_ntail(int kp) { return (kp - 16 * (kp / 16)
 
 __device__ __forceinline__ void load_afrag_st(const float *__restrict__ Xs, int ldx, int kp, int wave, int lane, AFrag &a) {
   const int g = lane >> 4, c = lane & 15;
-  const float *row = Xs + (16 * wave + c) * ldx;
+  const float *row = Xs + (16 * ddrl_rt(wave) + c) * ldx;
 #pragma unroll
   for (int kc = 0; kc < DDRL_MAXKC; ++kc)
     if (kc < st_full(kp)) a.v[kc] = *(const f32x4 *)(row + kc * 16 + 4 * g);
@@ -229,14 +277,21 @@ __device__ __forceinline__ void load_bfrag_st(const float *__restrict__ W, const
   b.t[0] = b.t[1] = b.t[2] = 0.01f;
   return;
 #endif
-  b.bias = bias[nt * 16 + c < N ? nt * 16 + c : N - 1];
+  b.bias = *lane_at(bias, fresh_lane((unsigned)(nt * 16 + c < N ? nt * 16 + c : N - 1)));
+  const unsigned lo = fresh_lane((unsigned)(c * 16 + 4 * g));
+  // scalar bases the compiler cannot fold back into the lanes' offsets (opaque), one per 4 KiB of the strip: every load is then
+  // base register pair + lane offset + immediate
+  const float *sb0 = opaque_base(W + ddrl_tile_base(nt, 0, kp)), *sb1 = st_full(kp) > 4 ? opaque_base(W + ddrl_tile_base(nt, 4, kp)) : sb0;
 #pragma unroll
   for (int kc = 0; kc < DDRL_MAXKC; ++kc)
-    if (kc < st_full(kp)) b.v[kc] = *(const f32x4 *)(W + ddrl_tile_base(nt, kc, kp) + c * 16 + 4 * g);
+    if (kc < st_full(kp))
+      b.v[kc] = *(const f32x4 *)lane_at((kc < 4 ? sb0 : sb1) + (ddrl_tile_base(nt, kc, kp) - ddrl_tile_base(nt, kc < 4 ? 0 : 4, kp)), lo);
   const int tw = kp - 16 * st_full(kp);
+  const unsigned lt = st_ntail(kp) > 0 ? fresh_lane((unsigned)(c * tw + g)) : 0u;
+  const float *sbt = st_ntail(kp) > 0 ? opaque_base(W + ddrl_tile_base(nt, st_full(kp), kp)) : sb0;
 #pragma unroll
   for (int e = 0; e < 3; ++e)
-    if (e < st_ntail(kp)) b.t[e] = W[ddrl_tile_base(nt, st_full(kp), kp) + c * tw + 4 * e + g];
+    if (e < st_ntail(kp)) b.t[e] = *lane_at(sbt + 4 * e, lt);
 }
 
 __device__ __forceinline__ f32x4 row_tile_st(const AFrag &a, const BFrag &b, int kp) {
@@ -271,16 +326,18 @@ __device__ __forceinline__ void load_wcol_st(const float *__restrict__ W, int kp
   const int np = ddrl_roundup(N, 4);
   const int kw = ddrl_tile_kw(kt, kp);
   const int cc = c < kw ? c : kw - 1;
+  const unsigned lo = fresh_lane((unsigned)(4 * g * kw + cc)), lt = fresh_lane((unsigned)(g * kw + cc));
 #pragma unroll
   for (int nc = 0; nc < DDRL_MAXKC; ++nc)
     if (nc < st_full(np)) {
-      const float *blk = W + ddrl_tile_base(nc, kt, kp) + 4 * g * kw + cc;
+      const float *sb = opaque_base(W + ddrl_tile_base(nc, kt, kp));      // (see load_bfrag_st)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b.v[nc][j] = blk[j * kw];
+      for (int j = 0; j < 4; ++j) b.v[nc][j] = *lane_at(sb + j * kw, lo);
     }
+  const float *sbt = st_ntail(np) > 0 ? opaque_base(W + ddrl_tile_base(st_full(np), kt, kp)) : W;
 #pragma unroll
   for (int e = 0; e < 3; ++e)
-    if (e < st_ntail(np)) b.t[e] = W[ddrl_tile_base(st_full(np), kt, kp) + (4 * e + g) * kw + cc];
+    if (e < st_ntail(np)) b.t[e] = *lane_at(sbt + 4 * e * kw, lt);
 }
 
 __device__ __forceinline__ f32x4 dx_tile_st(const AFrag &a, const WCol &b, int N) {
@@ -426,18 +483,21 @@ __device__ __forceinline__ void bwd_dx(const float *__restrict__ dYs, int ldy, i
   W = opaque(W);
   AFrag a;
   if (ST) {
+    // tile slot i of this wave's part is column tile kt0 + part + DDRL_PARTS i (one part: kt0 + i); a slot beyond the last
+    // tile repeats it (its accumulator is never stored)
     load_afrag_st(dYs, ldy, ddrl_roundup(N, 4), wave, lane, a);
+    const int part = ddrl_part(wave), ns = ddrl_slots(kt1 - kt0);
+    auto tile = [&](int i) { const int kt = kt0 + part + DDRL_PARTS * i; return kt < kt1 ? kt : kt1 - 1; };
     WCol b0, b1;
-    if (kt0 < kt1) load_wcol_st(W, kp, N, kt0, lane, b0);
+    if (0 < ns) load_wcol_st(W, kp, N, tile(0), lane, b0);
 #pragma unroll
     for (int i = 0; i < DDRL_MAXKC; i += 2) {
-      const int kt = kt0 + i;
-      if (kt < kt1) {
-        if (kt + 1 < kt1) load_wcol_st(W, kp, N, kt + 1, lane, b1);
+      if (i < ns) {
+        if (i + 1 < ns) load_wcol_st(W, kp, N, tile(i + 1), lane, b1);
         acc[i] = dx_tile_st(a, b0, N);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < kt1) {
-          if (kt + 2 < kt1) load_wcol_st(W, kp, N, kt + 2, lane, b0);
+        if (i + 1 < ns) {
+          if (i + 2 < ns) load_wcol_st(W, kp, N, tile(i + 2), lane, b0);
           acc[i + 1] = dx_tile_st(a, b1, N);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -549,22 +609,34 @@ struct OptRegs { f32x4 w, m, v, wt, fisher, fhat, wstar; };
 
 // EWC: the net has Fisher / anchor arrays (DODevMLP.hpp:604-707).  TGT: the net has a target twin
 // that is soft-updated in the same pass (MLP.hpp:437-452).
-template <bool EWC, bool TGT, bool NT = true>
-__device__ __forceinline__ void opt_load4(const OptCtx &o, int i, OptRegs &r) {
+// `at` maps an array's (uniform) base pointer to this lane's element: base + i, or lane_at(base + u, l) (element index split
+// into its wave-uniform and per-lane parts)
+struct AtIndex { int i; __device__ __forceinline__ const float *operator()(const float *b) const { return b + i; }
+                 __device__ __forceinline__ float *operator()(float *b) const { return b + i; }
+                 __device__ __forceinline__ AtIndex fresh() const { return *this; } };
+struct AtSplit { int u; unsigned l; __device__ __forceinline__ const float *operator()(const float *b) const { return lane_at(b + u, l); }
+                 __device__ __forceinline__ float *operator()(float *b) const { return lane_at(b + u, l); }
+                 __device__ __forceinline__ AtSplit fresh() const { return AtSplit{u, fresh_lane(l)}; } };
+
+template <bool EWC, bool TGT, bool NT = true, class AT>
+__device__ __forceinline__ void opt_load4_at(const OptCtx &o, const AT at0, OptRegs &r) {
 #if defined(DDRL_EXP_NOOPTMEM) || defined(DDRL_EXP_NOOPTLD)
-  r.w = r.m = r.v = r.wt = r.fisher = r.fhat = r.wstar = (f32x4){(float)i, 1.f, 2.f, 3.f};
+  r.w = r.m = r.v = r.wt = r.fisher = r.fhat = r.wstar = (f32x4){1.5f, 1.f, 2.f, 3.f};
   return;
 #endif
-  r.w = *(const f32x4 *)(o.w + i);
-  r.m = stream_ld<NT>(o.mld + i);
-  r.v = stream_ld<NT>(o.v + i);
-  if (TGT) r.wt = *(const f32x4 *)(o.wt + i);
+  const AT at = at0.fresh();
+  r.w = *(const f32x4 *)at(o.w);
+  r.m = stream_ld<NT>(at(o.mld));
+  r.v = stream_ld<NT>(at((const float *)o.v));
+  if (TGT) r.wt = *(const f32x4 *)at((const float *)o.wt);
   if (EWC) {
-    r.fisher = stream_ld<NT>(o.fisher + i);
-    r.fhat = stream_ld<NT>(o.fhat + i);
-    r.wstar = stream_ld<NT>(o.wstar + i);
+    r.fisher = stream_ld<NT>(at((const float *)o.fisher));
+    r.fhat = stream_ld<NT>(at(o.fhat));
+    r.wstar = stream_ld<NT>(at(o.wstar));
   }
 }
+template <bool EWC, bool TGT, bool NT = true>
+__device__ __forceinline__ void opt_load4(const OptCtx &o, int i, OptRegs &r) { opt_load4_at<EWC, TGT, NT>(o, AtIndex{i}, r); }
 
 // Four parameters: Fisher EMA (DODevMLP.hpp:651), EWC penalty (DODevMLP.hpp:702; ewc_coef is 0 and
 // fhat / wstar are all-zero until the first ewc_setup), L2 decay (caffe SGDSolver::Regularize; decay
@@ -582,8 +654,8 @@ __device__ __forceinline__ float uni(float x) {
 #endif
 }
 
-template <bool EWC, bool TGT, bool NT = true, bool PRED = true>     // PRED false: every lane stores (its index is a parameter's or the dump's)
-__device__ __forceinline__ void opt_step4(const OptCtx &o, int i, f32x4 grad, const OptRegs &r, bool ok) {
+template <bool EWC, bool TGT, bool NT = true, bool PRED = true, class AT>     // PRED false: every lane stores (its index is a parameter's or the dump's)
+__device__ __forceinline__ void opt_step4_at(const OptCtx &o, const AT at0, f32x4 grad, const OptRegs &r, bool ok) {
   f32x4 w = r.w, m, v, f, wt;
   if (EWC) {
     f = r.fisher * uni(o.fisher_beta) + (grad * grad) * uni(o.nsample);
@@ -600,20 +672,26 @@ __device__ __forceinline__ void opt_step4(const OptCtx &o, int i, f32x4 grad, co
   ok = ok && (w[0] + wt[1] + m[2] + v[3] + (EWC ? f[0] : 0.f) == 12345.678f);
 #endif
   if (!PRED || ok) {                          // stores only: nothing waits on them
+    const AT at = at0.fresh();
     if (o.handoff) {                          // uniform
-      if (EWC) store_sc1(o.fisher + i, f);
-      store_sc1(o.m + i, m);
-      store_sc1(o.v + i, v);
-      store_sc1(o.w + i, w);
-      if (TGT) store_sc1(o.wt + i, wt);
+      if (EWC) store_sc1(at(o.fisher), f);
+      store_sc1(at(o.m), m);
+      store_sc1(at(o.v), v);
+      store_sc1(at(o.w), w);
+      if (TGT) store_sc1(at(o.wt), wt);
     } else {
-      if (EWC) stream_st<NT>(o.fisher + i, f);
-      stream_st<NT>(o.m + i, m);
-      stream_st<NT>(o.v + i, v);
-      *(f32x4 *)(o.w + i) = w;
-      if (TGT) *(f32x4 *)(o.wt + i) = wt;
+      const AT at = at0.fresh();
+      if (EWC) stream_st<NT>(at(o.fisher), f);
+      stream_st<NT>(at(o.m), m);
+      stream_st<NT>(at(o.v), v);
+      *(f32x4 *)at(o.w) = w;
+      if (TGT) *(f32x4 *)at(o.wt) = wt;
     }
   }
+}
+template <bool EWC, bool TGT, bool NT = true, bool PRED = true>
+__device__ __forceinline__ void opt_step4(const OptCtx &o, int i, f32x4 grad, const OptRegs &r, bool ok) {
+  opt_step4_at<EWC, TGT, NT, PRED>(o, AtIndex{i}, grad, r, ok);
 }
 
 // scalar form (biases)
@@ -867,14 +945,14 @@ template <int NSETS> struct OptCarry { OptRegs r[NSETS]; };      // (a slot's el
 
 // element index of lane (c, g)'s four parameters in tile slot p, and the lane whose gradient they take (itself, or
 // lane (c, 0) beyond a short k-block)
-__device__ __forceinline__ int dw_elem_u(int p, int total, int KT, int N, int kp, int offw, int c, int g, int &src) {
+__device__ __forceinline__ AtSplit dw_elem_u(int p, int total, int KT, int N, int kp, int offw, int c, int g, int &src) {
   const int pc = p < total ? p : total - 1;
   const int nt = pc / KT, kt = pc - nt * KT;
   const int kw = ddrl_tile_kw(kt, kp);
   const int gg = 4 * g < kw ? g : 0;
   const int cc = nt * 16 + c < N ? c : N - 1 - nt * 16;      // pad rows of the last strip: the strip's last real row
   src = 16 * gg + cc;
-  return offw + ddrl_tile_base(nt, kt, kp) + cc * kw + 4 * gg;
+  return AtSplit{offw + ddrl_tile_base(nt, kt, kp), (unsigned)(cc * kw + 4 * gg)};      // the tile (uniform) + the lane's place in it
 }
 
 template <bool EWC, bool TGT, int NSETS>
@@ -886,7 +964,7 @@ __device__ __forceinline__ void dw_opt_request(int N, int kp, int offw, const Op
   for (int q = 0; q < NSETS - 1; ++q)
     if (q < per) {
       int src;
-      opt_load4<EWC, TGT>(o, dw_elem_u(p0 + q, total, KT, N, kp, offw, c, g, src), cy.r[q]);
+      opt_load4_at<EWC, TGT>(o, dw_elem_u(p0 + q, total, KT, N, kp, offw, c, g, src), cy.r[q]);
     }
 }
 
@@ -906,7 +984,7 @@ __device__ __forceinline__ void bwd_dw_opt_ct(const float *__restrict__ dYs, int
   for (int s = 0; s < per; ++s) {
     if (s + NSETS - 1 < per) {
       int src;
-      opt_load4<EWC, TGT>(o, dw_elem_u(p0 + s + NSETS - 1, total, KT, N, kp, offw, c, g, src), cy.r[(s + NSETS - 1) % NSETS]);
+      opt_load4_at<EWC, TGT>(o, dw_elem_u(p0 + s + NSETS - 1, total, KT, N, kp, offw, c, g, src), cy.r[(s + NSETS - 1) % NSETS]);
     }
     const int q = s % NSETS;
     if (p0 + s < total) {                      // uniform; false only for a wave's trailing slots
@@ -916,10 +994,10 @@ __device__ __forceinline__ void bwd_dw_opt_ct(const float *__restrict__ dYs, int
       f32x4 acc = dw_tile(dYs, ldy, N, Xs, ldx, kp, p0 + s, total, KT, c, g);
 #endif
       int src;
-      const int i = dw_elem_u(p0 + s, total, KT, N, kp, offw, c, g, src);
+      const AtSplit i = dw_elem_u(p0 + s, total, KT, N, kp, offw, c, g, src);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] = __shfl(acc[e], src);
-      opt_step4<EWC, TGT, true, false>(o, i, acc, cy.r[q], true);
+      opt_step4_at<EWC, TGT, true, false>(o, i, acc, cy.r[q], true);
     }
     __builtin_amdgcn_sched_barrier(0);
   }

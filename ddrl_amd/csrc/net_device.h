@@ -44,10 +44,16 @@ __device__ __forceinline__ FwdNext fwd_first(const ND &nd, const float *__restri
   FwdNext nx = {w + nd.offw(0), w + nd.offb(0), nd.kp(0), nd.d(1)};
   return nx;
 }
-__device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry &cy) {     // (compile-time shapes only: the short-tail fragment form)
+// the column tile behind tile slot t of this wave's part in a layer of NT column tiles (mlp_device.h, DDRL_PARTS), clamped
+__device__ __forceinline__ int fwd_slot_tile(int t, int NT, int part) {
+  const int nt = part + DDRL_PARTS * t;
+  return nt < NT ? nt : NT - 1;
+}
+__device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry &cy, int wave = 0) {     // (compile-time shapes only: the short-tail fragment form)
   const float *W = opaque(nx.W), *bias = opaque(nx.bias);
-  load_bfrag_st(W, bias, nx.kp, nx.N, 0, lane, cy.b0);
-  if (16 < nx.N) load_bfrag_st(W, bias, nx.kp, nx.N, 1, lane, cy.b1);
+  const int NT = (nx.N + 15) >> 4, part = ddrl_part(wave);
+  load_bfrag_st(W, bias, nx.kp, nx.N, fwd_slot_tile(0, NT, part), lane, cy.b0);
+  if (1 < ddrl_slots(NT)) load_bfrag_st(W, bias, nx.kp, nx.N, fwd_slot_tile(1, NT, part), lane, cy.b1);
 }
 
 // ---- compile-time shapes: the whole pass as ONE static schedule ----
@@ -60,9 +66,9 @@ __device__ __forceinline__ void fwd_request(const FwdNext nx, int lane, FwdCarry
 // Hand-over convention (unchanged): a pass starts with its tiles 0 / 1 in cy.b0 / cy.b1; that is where this pass leaves
 // them for its successor when its tile count is a multiple of three (true for every instantiated net), else the successor
 // starts cold.
-template <class ND> __host__ __device__ constexpr int fwd_pass_tiles(int nl) {
+template <class ND> static __host__ __device__ constexpr int fwd_pass_tiles(int nl) {
   int t = 0;
-  for (int l = 0; l < nl; ++l) t += (ND::d(l + 1) + 15) / 16;
+  for (int l = 0; l < nl; ++l) t += ddrl_slots((ND::d(l + 1) + 15) / 16);      // tile SLOTS of one part
   return t;
 }
 template <class ND, bool HAS_AFTER>
@@ -70,28 +76,29 @@ __device__ __forceinline__ void fwd_net_ct(const ND &nd, int nl, const float *__
                                            const float *X, int ldx, float *hbase, int hstride, float *top, int ldtop,
                                            int wave, int lane, FwdCarry &cy, bool preloaded, const FwdNext after) {
   const int g = lane >> 4, c = lane & 15;
+  const int part = ddrl_part(wave), rt = ddrl_rt(wave);
   BFrag b2;
   const float *wo = opaque(w);
   const float *aW = HAS_AFTER ? opaque(after.W) : nullptr, *ab = HAS_AFTER ? opaque(after.bias) : nullptr;
   const bool hand = HAS_AFTER && fwd_pass_tiles<ND>(nl) % 3 == 0;
-  // request tile `t` of layer `l` (or, past the last layer of the pass, of the successor) into fragment set `set`
+  // request tile SLOT `t` of layer `l` (or, past the last layer of the pass, of the successor) into fragment set `set`
   auto request = [&](int l, int t, int set) {
-    // walk forward over layers whose tiles are exhausted (folds: every bound is a constant)
+    // walk forward over layers whose slots are exhausted (folds: every bound is a constant)
     bool done = false;
 #pragma unroll
     for (int step = 0; step <= DDRL_MAXL; ++step) {
       if (!done && l < nl) {
         const int NTl = (nd.d(l + 1) + 15) >> 4;
-        if (t < NTl) {
+        if (t < ddrl_slots(NTl)) {
           BFrag &dst = set == 0 ? cy.b0 : set == 1 ? cy.b1 : b2;
-          load_bfrag_st(wo + nd.offw(l), wo + nd.offb(l), nd.kp(l), nd.d(l + 1), t, lane, dst);
+          load_bfrag_st(wo + nd.offw(l), wo + nd.offb(l), nd.kp(l), nd.d(l + 1), fwd_slot_tile(t, NTl, part), lane, dst);
           done = true;
-        } else { t -= NTl; ++l; }
+        } else { t -= ddrl_slots(NTl); ++l; }
       }
     }
-    if (!done && hand && l >= nl && t < 2 && t * 16 < after.N) {
+    if (!done && hand && l >= nl && t < 2 && t < ddrl_slots((after.N + 15) >> 4)) {
       BFrag &dst = set == 0 ? cy.b0 : set == 1 ? cy.b1 : b2;
-      load_bfrag_st(aW, ab, after.kp, after.N, t, lane, dst);
+      load_bfrag_st(aW, ab, after.kp, after.N, fwd_slot_tile(t, (after.N + 15) >> 4, part), lane, dst);
     }
   };
   if (!preloaded) { request(0, 0, 0); request(0, 1, 1); }
@@ -107,25 +114,26 @@ __device__ __forceinline__ void fwd_net_ct(const ND &nd, int nl, const float *__
       const int NT = (N + 15) >> 4;
       AFrag a;
       load_afrag_st(in, ldi, kp, wave, lane, a);
-      float *yrow = out + (16 * wave + 4 * g) * ldo;
+      float *yrow = out + (16 * rt + 4 * g) * ldo;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt, ++j) {
-        request(l, nt + 2, (j + 2) % 3);
+      for (int t = 0; t < ddrl_slots(NT); ++t, ++j) {
+        request(l, t + 2, (j + 2) % 3);
         const BFrag &b = j % 3 == 0 ? cy.b0 : j % 3 == 1 ? cy.b1 : b2;
         const f32x4 acc = row_tile_st(a, b, kp);
-        const int n = nt * 16 + c;
-        if (n < ldo) {
+        const int n = fwd_slot_tile(t, NT, part) * 16 + c;
+        if (n < ldo && (DDRL_PARTS == 1 || part + DDRL_PARTS * t < NT)) {      // (uniform) a slot beyond the last tile stores nothing
 #pragma unroll
           for (int r = 0; r < 4; ++r) yrow[r * ldo + n] = n < N ? act_fwd(act, acc[r] + b.bias) : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      wave_lds_fence();
+      // one wave per row tile: its own LDS ordering is enough; two: the row's other columns are the partner's
+      if (DDRL_PARTS == 1) wave_lds_fence(); else ddrl_sync();
       in = out;
       ldi = ldo;
     }
   }
-  ddrl_sync();
+  if (DDRL_PARTS == 1) ddrl_sync();
 }
 
 template <class ND, bool HAS_AFTER = true>
@@ -185,7 +193,7 @@ __device__ __forceinline__ void fwd_net(const ND &nd, int nl, const float *__res
 enum { DW_NONE = 0, DW_OPT = 1, DW_STORE = 2 };
 template <class ND> struct KParkOf { static constexpr bool value = ND::kPark; };
 template <> struct KParkOf<NetDesc> { static constexpr bool value = false; };
-#define DDRL_PARK_TILES 4     // input-gradient tiles (of up to DDRL_MAXKC) parked in LDS during a deep layer's optimiser loop
+#define DDRL_PARK_TILES (4 / DDRL_PARTS)     // input-gradient tiles (of up to DDRL_MAXKC) parked in LDS during a deep layer's optimiser loop
 // TGT: the optimiser epilogue also moves the net's target twin (false: TD3's critics between two policy steps)
 template <int TRAIN, bool EWC, bool TGT = true, class ND, class DX0>
 __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ w, const OptCtx &opt, float *gout,
@@ -193,7 +201,9 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
                                         int c0, int nc, DX0 dx0_store, int wave, int lane, int tid,
                                         long long *bst = nullptr,     // bst: diagnostic s_memtime slots (dX done / dW done per layer)
                                         float *park = nullptr) {      // park: DDRL_PARK_TILES * 1 KiB of LDS per wave, dead during the dW loops below the top layer
+  static_assert(DDRL_PARTS == 1 || !__is_same(ND, NetDesc), "column parts: compile-time shapes only");
   const int g = lane >> 4, c = lane & 15;
+  const int part = ddrl_part(wave), rt = ddrl_rt(wave);
   float *dZ = top;
   int ldz = ldtop;
 #pragma unroll
@@ -237,7 +247,7 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
         if (deep && need_dx) {
 #pragma unroll
           for (int i = 0; i < DDRL_PARK_TILES; ++i)
-            if (kt0 + i < kt1) *(f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4) = acc[i];
+            if (i < ddrl_slots(kt1 - kt0)) *(f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4) = acc[i];
         }
         if constexpr (CT) {
           if (deep_ct && l < nd.L() - 1) bwd_dw_opt_ct<EWC, TGT, 3>(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), opt, wave, lane, tid, oc3, true);
@@ -249,7 +259,7 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
         if (deep && need_dx) {
 #pragma unroll
           for (int i = 0; i < DDRL_PARK_TILES; ++i)
-            if (kt0 + i < kt1) acc[i] = *(const f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4);
+            if (i < ddrl_slots(kt1 - kt0)) acc[i] = *(const f32x4 *)(park + (wave * DDRL_PARK_TILES + i) * 256 + lane * 4);
         }
       }
       else bwd_dw_store(dZ, ldz, N, in, ldi, kp, nd.offw(l), nd.offb(l), gout, wave, lane, tid, opt.handoff != 0);
@@ -259,12 +269,12 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
     if (need_dx) {
 #pragma unroll
       for (int i = 0; i < DDRL_MAXKC; ++i) {
-        const int kt = kt0 + i;
-        if (kt < kt1) {
+        const int kt = kt0 + part + DDRL_PARTS * i;          // the column tile of this wave's slot i (bwd_dx)
+        if (i < ddrl_slots(kt1 - kt0) && kt < kt1) {
           const int col = kt * 16 + c;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wave + 4 * g + r;
+            const int row = 16 * rt + 4 * g + r;
             if (l > 0) {
               if (col < K) in[row * ldi + col] = act_bwd(nd.hidden_act(), in[row * ldi + col], acc[i][r]);
             } else if (col >= c0 && col < c0 + nc) {
@@ -273,7 +283,7 @@ __device__ __forceinline__ void bwd_net(const ND &nd, const float *__restrict__ 
           }
         }
       }
-      wave_lds_fence();
+      if (DDRL_PARTS == 1) wave_lds_fence(); else ddrl_sync();     // (two waves per row tile: the partner wrote the other columns)
     }
     dZ = in;
     ldz = ldi;

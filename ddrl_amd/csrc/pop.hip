@@ -31,6 +31,8 @@ int ddpg_update_pair_pays(const DdpgParams *P);
 int ddpg_update_loop_ok(const DdpgParams *P);
 int ddpg_update_loop_pays(const DdpgParams *P);
 hipError_t ddpg_update_loop_launch(const DdpgParams *P, hipStream_t st);
+int ddpg_update_loop8_ok(const DdpgParams *P);
+hipError_t ddpg_update_loop8_launch(const DdpgParams *P, hipStream_t st);
 hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st);
 size_t ddpg_update_bn_lds_bytes(const DdpgParams *P);
 hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G, hipStream_t st);
@@ -701,7 +703,13 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   // (ddpg_update_loop_kernel); option "loop" 0 falls back to one workgroup per (update, agent) with the sc1 hand-off
   const bool loop = fused && !h->force_generic && h->loop_mode > 0 && per_launch >= 2 && !pair && !resident && ddpg_update_loop_ok(&h->P) &&
                     (h->loop_mode == 2 || ddpg_update_loop_pays(&h->P));
-  h->P.pair = pair || resident || loop ? 1 : 0;
+  // opt-in (option "w8": 0 never (default), 1 up to DDRL_W8_MAX_AGENTS agents, 2 always): the same loop with eight waves per agent
+  // (kernels_ddpg_w8.hip), meant for populations that leave CUs without a second workgroup.  Measured SLOWER than four waves
+  // (128 agents: 1.19 M against 1.26 M updates/s): the update is bound by what a SIMD can issue (fp32 MFMAs run on the vector
+  // ALU), not by the waits a second wave could fill, and the shared row tiles cost a barrier per layer
+  const bool w8 = fused && !h->force_generic && h->w8_mode > 0 && !pair && !resident && ddpg_update_loop8_ok(&h->P) &&
+                  (h->w8_mode == 2 || (h->loop_mode > 0 && G <= DDRL_W8_MAX_AGENTS));
+  h->P.pair = pair || resident || loop || w8 ? 1 : 0;
   std::vector<int32_t> one;
   for (int l = 0; l < n; l += per_launch) {
     if (idx) {
@@ -734,13 +742,14 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
     else if (!fused) HIPCHK(ddpg_update_big_launch(&h->P, h->stream));
     else if (resident) HIPCHK(ddpg_update_resident_launch(&h->P, h->stream));
     else if (pair) HIPCHK(ddpg_update_pair_launch(&h->P, h->stream));
+    else if (w8) HIPCHK(ddpg_update_loop8_launch(&h->P, h->stream));
     else if (loop) HIPCHK(ddpg_update_loop_launch(&h->P, h->stream));
     else HIPCHK(ddpg_update_launch(&h->P, h->force_generic, h->stream));
     if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
   }
   h->P.pair = 0;
   if (h->bn && (rc = refresh_testing(h))) return rc;        // DeepQNAg.hpp:469-472, after the fupd loop
-  if (per_launch > 1 || pair || resident || loop) h->multi_pending = true;     // every kernel that can raise the error word (team barriers too)
+  if (per_launch > 1 || pair || resident || loop || w8) h->multi_pending = true;     // every kernel that can raise the error word (team barriers too)
   if (idx || mask) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
 }
@@ -1291,6 +1300,7 @@ extern "C" int ddrl_pop_set_option(ddrl_pop_t *h, const char *key, int value) {
     return DDRL_OK;
   }
   if (std::string(key) == "loop") { h->loop_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
+  if (std::string(key) == "w8") { h->w8_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "pair") { h->pair_mode = value < 0 ? 0 : value > 2 ? 2 : value; return DDRL_OK; }
   if (std::string(key) == "force_chunked") {     // the gradient + apply kernels of the large-minibatch path on one-tile minibatches
     DDPG_ONLY(h);

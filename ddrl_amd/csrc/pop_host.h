@@ -95,6 +95,7 @@ struct ddrl_pop {
   std::vector<double> gate_w_s, gate_w_a;   // the gate WEIGHTS [G x S], [G x A] the flat view shows (the device holds the factors made of them)
   std::vector<int> st_control, ac_control;
   bool st_layer = false, ac_layer = false, gates_learnable = false;
+  int w8_mode = 0;            // eight waves per agent (kernels_ddpg_w8.hip): 0 never (default: measured slower than four waves, 1.19 M against 1.26 M updates/s at 128 agents), 1 up to DDRL_W8_MAX_AGENTS agents, 2 always
   int loop_mode = 1;          // multi-update launches keep an agent's updates in one workgroup (ddpg_update_loop_kernel): 0 never, 1 where it pays (mid nets), 2 whenever the shapes are compile-time ones
 };
 

@@ -46,6 +46,7 @@ typedef float ddrl_f32;        // a real fp32 where an outside API wants one (hi
 #define DDRL_NWAVES 4        // 256-thread workgroups, one wave per SIMD: each wave carries 16 of the 64 batch rows (mlp_device.h);
 #endif                       // two workgroups per CU (LDS, and 256 VGPRs per wave) => two waves per SIMD
 #define DDRL_NTHREADS (DDRL_NWAVES * 64)
+#define DDRL_W8_MAX_AGENTS 256  // populations up to this size run eight waves per agent (kernels_ddpg_w8.hip): one workgroup per CU at most
 #define DDRL_PAIR_MIN_UPD 4     // shortest launch (updates per agent) that runs as agent pairs (kernels_ddpg_pair.hip: one idle quarter per launch)
 #define DDRL_MAXUPD 64       // consecutive updates one launch may run (ddrl_pop_ddpg_update_n)
 #define DDRL_MAXB 4096       // largest minibatch (chunks of DDRL_MB rows, kernels_ddpg_big.hip)

@@ -376,11 +376,12 @@ def test_xcd_order_many_agents(ora, G, B, hidden_a, hidden_q):
 def _multi_update_mode(pop, mode):
     """which kernel runs a multi-update launch of the compile-time shapes: the in-workgroup loop (the default for mid nets),
     agent pairs, or one workgroup per (update, agent) with the sc1 hand-off"""
-    pop.set_option("loop", {"loop": 2, "pair": 0, "handoff": 0}[mode])
-    pop.set_option("pair", {"loop": 0, "pair": 2, "handoff": 0}[mode])
+    pop.set_option("loop", {"loop": 2, "pair": 0, "handoff": 0, "w8": 2}[mode])
+    pop.set_option("pair", {"loop": 0, "pair": 2, "handoff": 0, "w8": 0}[mode])
+    pop.set_option("w8", 2 if mode == "w8" else 0)      # "w8": eight waves per agent (kernels_ddpg_w8.hip; mid nets only, else the loop kernel)
 
 
-@pytest.mark.parametrize("pair", ["loop", "pair", "handoff"])
+@pytest.mark.parametrize("pair", ["loop", "pair", "handoff", "w8"])
 @pytest.mark.parametrize("B,hidden,kw", [(64, (100, 100), dict()), (32, (20,), dict(nstep_return=2, goal_prob=0.1)), (96, (24, 16), dict())])
 def test_fused_consecutive_updates(ora, B, hidden, kw, pair):
     """ddrl_pop_ddpg_update_n: n passes of the fupd loop in one launch (one-tile minibatches) == n calls of
@@ -392,6 +393,7 @@ def test_fused_consecutive_updates(ora, B, hidden, kw, pair):
     popa, agents = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
     _multi_update_mode(popa, pair)
     popb, _ = make_pair(ora, G=G, B=B, hidden_a=hidden, hidden_q=hidden, wscale=0.1, sweep=True, seed=5, **kw)
+    popb.set_option("w8", 0)                  # the single-update reference: always the four-wave kernel
     mask = np.array([1, 0, 1], np.uint8)
     popa.update_n(n, mask=mask)
     used = []
@@ -461,7 +463,7 @@ def test_resident_small_nets(ora, ewc):
     assert list(popa.adam(0)[2]) == [1 + 2 * n, 1 + 2 * n, 1, 1 + 2 * n, 1 + 2 * n]
 
 
-@pytest.mark.parametrize("pair", ["loop", "pair", "handoff"])
+@pytest.mark.parametrize("pair", ["loop", "pair", "handoff", "w8"])
 def test_fused_consecutive_updates_full_chip(pair):
     """the same identity at the bench's scale, EWC live.  pair = 0: 8 x 1100 workgroups against 512 resident slots, so
     an agent's consecutive updates run in different dispatch rounds, on different CUs and XCDs (the sc1 hand-off);
@@ -485,6 +487,7 @@ def test_fused_consecutive_updates_full_chip(pair):
         pops.append(p)
     a, b = pops
     _multi_update_mode(a, pair)
+    b.set_option("w8", 0)
     for _ in range(2):
         a.update_n(n)
         for _ in range(n):
@@ -563,3 +566,50 @@ def test_error_word_blocks_every_reader_of_state(ora, tmp_path):
             rd(pop)
         assert e.value.code == -4 and "skipped" in str(e.value)          # DDRL_ESTATE
         rd(pop)                                                            # reported once, then the handle answers again
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(ewc=100.0, ewc_for_critic=1), dict(B=40, inverting_grad=1), dict(nstep_return=3, goal_prob=0.1),
+                                dict(gates="det"), dict(gates="bern", ewc=10.0)])
+def test_eight_waves_per_agent_bit_identical(ora, kw):
+    """kernels_ddpg_w8.hip (512-thread workgroups, two waves per 16-row tile; the default for populations of up to 256 agents of
+    the mid nets) against the four-wave kernels: single updates and multi-update launches, bit for bit -- weights, targets, Adam
+    state, Fisher, diagnostics -- with EWC live, a short minibatch, n-step targets, deterministic and Bernoulli gates, a mask."""
+    kw = dict(kw)
+    B = kw.pop("B", 64)
+    gates = kw.pop("gates", None)
+    ewc = "ewc" in kw
+    G, n = 5, 3
+    pops = []
+    for w8 in (2, 0):
+        p, _ = make_pair(ora, G=G, B=B, hidden_a=(100, 100), hidden_q=(100, 100), wscale=0.1, sweep=True, seed=13, **kw)
+        p.set_option("w8", w8)
+        if gates:
+            rng = np.random.RandomState(2)
+            if gates == "det":
+                p.set_gates((rng.uniform(0, 1, (G, 18)) < 0.7).astype(np.float64), (rng.uniform(0, 1, (G, 6)) < 0.7).astype(np.float64))
+            else:
+                p.set_gates(rng.uniform(0.3, 1, (G, 18)), rng.uniform(0.3, 1, (G, 6)))
+                p.set_gate_mode(1, 1, 1, 0, seed=21)
+        pops.append(p)
+    a, b = pops
+    mask = np.array([1, 1, 0, 1, 1], np.uint8)
+    for p in pops:
+        p.update()
+        if ewc:
+            p.update_best_param(np.ones(G)); p.ewc_setup()
+        p.update(mask=mask)
+        p.update_n(n, mask=mask)
+        p.update_n(2)
+    for net in range(4):
+        assert np.array_equal(a.weights(net), b.weights(net)), net
+    for net in (0, 1):
+        for x, y in zip(a.adam(net), b.adam(net)):
+            assert np.array_equal(x, y)
+        if ewc and (net == 0 or kw.get("ewc_for_critic")):
+            sa, sb = a.ewc_state(net), b.ewc_state(net)
+            assert np.array_equal(sa["fisher"], sb["fisher"]) and np.array_equal(sa["fisher_nbr"], sb["fisher_nbr"])
+    la, lb = a.last(), b.last()
+    for k in la:
+        assert np.array_equal(la[k], lb[k]), k
+    assert list(a.adam(0)[2]) == [4 + n, 4 + n, 3, 4 + n, 4 + n]
+    a.close(); b.close()

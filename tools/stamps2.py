@@ -14,6 +14,8 @@ NU = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 cfg = ddrl_amd.DdpgConfig(n_agents=G, replay_memory=2000, ewc=100.0, ewc_for_critic=1, inverting_grad=1)
 pop = ddrl_amd.DdpgPopulation(cfg, init_seed=1)
 pop.set_option("pair", pair)
+if len(sys.argv) > 4:
+    pop.set_option("w8", int(sys.argv[4]))
 rows = synth_rows(0, 2000, 18, 6)
 for g in range(G):
     pop.replay_load(g, rows)
