@@ -114,6 +114,13 @@ ddpg_update_loop_kernel(const DdpgParams P) {
   if (!live || len < 250 || len < P.B) return;             // DeepQNAg.hpp:338 (uniform)
   GatherRegs pre;
   bool have_pre = ddpg_prefetch_rows<NA, NQ>(P, agent, 0, head, tid, pre);
+#ifdef DDRL_EXP_STAGGER   // experiment: spread the workgroups' phases over DDRL_EXP_STAGGER cycles (a population of one workgroup per CU runs in lockstep)
+  {
+    const long long t0 = clock64();
+    const long long delay = (long long)((((unsigned)agent * 2654435761u) >> 8) % (unsigned)DDRL_EXP_STAGGER);
+    while (clock64() - t0 < delay) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 #pragma unroll 1
   for (int u = 0; u < P.nupd; ++u) {
     int a_it = agent, tid_it = tid, z = 0;                    // nothing is hoisted out of this loop (see the pair kernel)

@@ -126,10 +126,10 @@ __device__ __forceinline__ unsigned fresh_lane(unsigned lane_floats) {
   return lane_floats;
 }
 __device__ __forceinline__ const float *lane_at(const float *ubase, unsigned lane_floats) {
-  return (const float *)((const char *)ubase + lane_floats * 4u);
+  return (const float *)((const char *)ubase + lane_floats * (unsigned)sizeof(float));
 }
 __device__ __forceinline__ float *lane_at(float *ubase, unsigned lane_floats) {
-  return (float *)((char *)ubase + lane_floats * 4u);
+  return (float *)((char *)ubase + lane_floats * (unsigned)sizeof(float));
 }
 
 // Cache warming without registers (EXPERIMENT switches DDRL_EXP_TOUCHW / DDRL_EXP_TOUCHSTATE only, never defined in the
