@@ -2,7 +2,7 @@
 // the reference's save_run / load_previous_run (DeepQNAg.hpp:504-537, CMAESAg.hpp:279-308; --continue,
 // Simulator.hpp:76-84,196-205) keep across a pre-emption, for a whole population in one file.
 //
-// A file is the magic "DDRLRUN1" followed by records [u32 tag length][tag][u64 payload bytes][payload].
+// A file is the magic "DDRLRUN2" (format version 2: round 3; files of version 1 are refused by the magic) followed by records [u32 tag length][tag][u64 payload bytes][payload].
 // ONE traversal function per object both writes and reads (Ckpt::writing picks the direction), so the two
 // cannot drift apart; on reading, every record's tag and size are checked against what the receiving
 // object expects, and a file from a different configuration is refused with DDRL_EIO before anything of
@@ -14,6 +14,10 @@
 #include <cstdio>
 #include <cstring>
 #include <unistd.h>
+#include <fcntl.h>
+#include <atomic>
+#include <string>
+#include <vector>
 #include "../../include/ddrl_pop.h"
 #include "host_util.h"
 
@@ -32,14 +36,16 @@ struct Ckpt {
     path = p; writing = w;
     // written next to the target and renamed over it once complete and on disk (finish): a pre-emption in the middle
     // of a multi-GB write -- the event run files exist for -- leaves the previous file intact
-    tmp = path + ".tmp";
+    // (the temporary's name is this process's and this writer's own: two handles or ranks saving to one target do not share it)
+    static std::atomic<unsigned> serial{0};
+    tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
     f = fopen(w ? tmp.c_str() : p, w ? "wb" : "rb");
     if (!f) return ddrl_fail(DDRL_EIO, "cannot open %s", w ? tmp.c_str() : p);
     if (!w) {                                                            // bounds every length a record may claim
       if (fseek(f, 0, SEEK_END) == 0) { const long e = ftell(f); file_bytes = e > 0 ? (uint64_t)e : 0; }
       rewind(f);
     }
-    char magic[8] = {'D', 'D', 'R', 'L', 'R', 'U', 'N', '1'};
+    char magic[8] = {'D', 'D', 'R', 'L', 'R', 'U', 'N', '2'};
     if (w) { if (fwrite(magic, 1, 8, f) != 8) return ddrl_fail(DDRL_EIO, "write to %s failed", p); return DDRL_OK; }
     char got[8];
     if (fread(got, 1, 8, f) != 8 || memcmp(got, magic, 8) != 0) return ddrl_fail(DDRL_EIO, "%s is not a ddrl_pop run file", p);
@@ -130,6 +136,12 @@ struct Ckpt {
     f = nullptr;
     if (writing && rc == DDRL_OK && rename(tmp.c_str(), path.c_str()) != 0) rc = ddrl_fail(DDRL_EIO, "cannot rename %s to %s", tmp.c_str(), path.c_str());
     if (writing && rc != DDRL_OK) remove(tmp.c_str());
+    if (writing && rc == DDRL_OK) {          // the rename itself reaches the disk with the directory (best effort: not every file system lets a directory be opened)
+      const size_t slash = path.find_last_of('/');
+      const std::string dir = slash == std::string::npos ? std::string(".") : slash == 0 ? std::string("/") : path.substr(0, slash);
+      const int dfd = ::open(dir.c_str(), O_RDONLY);
+      if (dfd >= 0) { (void)fsync(dfd); ::close(dfd); }
+    }
     return rc;
   }
 };

@@ -36,7 +36,9 @@ extern "C" {
 #define DDRL_EIO          -5   /* ini file problems */
 
 /* nets of a DDPG population (DeepQNAg.hpp:209-234): ann, qnn, ann_target, qnn_target.
- * ann_testing (DeepQNAg.hpp:221,469-472) is a full copy of ann after every update: aliased. */
+ * ann_testing (DeepQNAg.hpp:221,469-472) is a full copy of ann after every update: for nets without BatchNorm towers it is
+ * ann itself (aliased); with towers it is a TEST-phase copy of its own, refreshed after every update round and after every
+ * call that writes the actor. */
 #define DDRL_NET_ACTOR          0
 #define DDRL_NET_CRITIC         1
 #define DDRL_NET_ACTOR_TARGET   2
@@ -388,8 +390,10 @@ int ddrl_nfac_last(ddrl_pop_t *h, float *deltas, int32_t *n_pos, float *critic_l
  * fp32; sampling x = m + sigma * B (D o z) and the rank-mu covariance update are fp32-MFMA GEMMs,
  * ranking is an exact sort with c-cmaes' tie rule; the N-vectors (mean, ps, pc, D) and scalars are
  * fp64 on the device; the lazily scheduled eigendecomposition (cmaes.c:1885-1947) runs on the host
- * in fp64.  z comes from the reference's own generator (cmaes.c:2421-2482, sequential by
- * construction) evaluated on the host, so runs are reproducible against c-cmaes seed for seed.
+ * in fp64 by default (the reference's own tred2 / tql2 sequence: parity mode) or, option "device_eigen", on the GPU by
+ * this library's one-sided Jacobi kernels.  z comes from the reference's own generator (cmaes.c:2421-2482, sequential by
+ * construction) evaluated on the host by default, so runs are reproducible against c-cmaes seed for seed; option
+ * "device_rng" draws it on the GPU instead (throughput mode: another stream).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ddrl_cmaes ddrl_cmaes_t;
 
@@ -417,8 +421,9 @@ int ddrl_cmaes_update(ddrl_cmaes_t *h, const double *fitness);
 int ddrl_cmaes_update_dev(ddrl_cmaes_t *h, const double *d_fitness);
 /* Sorted_index (cmaes.c:2989-3000) on the GPU: ascending, equal values => later index first */
 int ddrl_cmaes_rank(ddrl_cmaes_t *h, const double *fitness, int n, int32_t *index_out);
-/* No counterpart in the reference: ddrl_cmaes_rank for callers that cannot allocate device memory (code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same ranking, same tie rule, no
+/* No counterpart in the reference: ddrl_cmaes_rank for callers that cannot allocate device memory (tight serving
+ * loops, harnesses that forbid hipMalloc).  It allocates nothing but it does WAIT for its stream before returning, so
+ * it is not for use inside a HIP graph capture.  Same ranking, same tie rule, no
  * handle: the device staging of the fitness values and of the index lives in a fixed 48-KiB array inside the
  * library (one per GPU, held until the process ends), so n <= 4096 (larger n: DDRL_EINVAL).  fitness [n] and
  * index_out [n] may be host or device pointers; `stream` is a hipStream_t (NULL = the default stream) of the
