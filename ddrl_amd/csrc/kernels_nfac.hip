@@ -240,8 +240,13 @@ nfac_grad_kernel(const NfacParams P, int iter_add, int last) {
   if (MODE == 0) {
     if (tid < DDRL_MB) {
       const int li = row0 + tid;
-      const float df = li < T ? M.top[tid * ldt] - P.tgt[ro + li] : 0.f;
+      float df = li < T ? M.top[tid * ldt] - P.tgt[ro + li] : 0.f;
       float sq = df * df;
+      if (P.lw) {          // (uniform) the weighted loss of learn_batch_lw: sum w (yhat - y)^2 / (2T), d yhat = w (yhat - y) / T
+        const float wl = li < T ? P.lw[ro + li] : 0.f;
+        sq *= wl;
+        df *= wl;
+      }
       for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
       if (tid == 0) store_sc1(P.loss_part + (size_t)agent * P.maxchunks + chunk, sq);
       M.top[tid * ldt] = df / (float)T;

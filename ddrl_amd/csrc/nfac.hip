@@ -25,7 +25,7 @@ struct NfacHost {
   uint8_t *d_endflag = nullptr;
   std::vector<int> h_len;
   std::vector<std::vector<int>> h_ends;       // trajectory_end_points per agent
-  float *d_V = nullptr, *d_nextV = nullptr, *d_tgt = nullptr, *d_deltas = nullptr, *d_gpart_a = nullptr, *d_gpart_v = nullptr,
+  float *d_V = nullptr, *d_nextV = nullptr, *d_tgt = nullptr, *d_lw = nullptr, *d_deltas = nullptr, *d_gpart_a = nullptr, *d_gpart_v = nullptr,
         *d_loss_part = nullptr, *d_loss = nullptr, *d_pa = nullptr;
   uint8_t *d_rowmode = nullptr;
   int *d_npos = nullptr;
@@ -375,6 +375,7 @@ extern "C" int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask) {
   HIPCHK(hipMemcpyAsync(n->d_endflag, flags.data(), flags.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(n->d_len, n->h_len.data(), G * sizeof(int), hipMemcpyHostToDevice, h->stream));
   n->P.mask = dmask;
+  n->P.lw = nullptr;
   n->P.generic = h->force_generic ? 1 : 0;
   n->P.fuse = h->nfac_fuse ? 1 : 0;
   n->P.sgate = h->gates_on ? h->d_sgate : nullptr;
@@ -403,6 +404,57 @@ extern "C" int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask) {
     n->h_ends[g].clear();
   }
   return ddrl_pop_ewc_decay_update(h, mask);     // :593-594
+}
+
+// MLP::learn_batch_lw (MLP.hpp:487-506) on the critic of every agent with mask[g] != 0: `iters` full-batch Adam steps on the n
+// rows (x, y) with label weights lw (null: learn_batch, MLP.hpp:468-485), EWC terms included when live.  The rows pass
+// through the agents' trajectory buffers, so nothing may be waiting there.
+extern "C" int ddrl_nfac_learn_batch_lw(ddrl_pop_t *h, const float *x, const float *y, const float *lw, int cnt, int iters, const uint8_t *mask) {
+  NFAC_ONLY(h);
+  NfacHost *n = h->nfac;
+  const ddrl_nfac_config &c = n->cfg;
+  const int G = h->G, maxT = c.max_trajectory, S = c.nb_sensors;
+  if (!x || !y || cnt <= 0 || cnt > maxT || iters < 0) return ddrl_fail(DDRL_EINVAL, "bad argument (1 <= n <= max_trajectory = %d)", maxT);
+  if (c.vnn_from_scratch) return ddrl_fail(DDRL_EINVAL, "learn_batch_lw with vnn_from_scratch is not supported");
+  for (int g = 0; g < G; ++g)
+    if ((!mask || mask[g]) && n->h_len[g] != 0)
+      return ddrl_fail(DDRL_ESTATE, "agent %d holds %d gathered transitions: learn_batch_lw would overwrite them", g, n->h_len[g]);
+  int rc = set_device(h);
+  if (rc) return rc;
+  const uint8_t *dmask;
+  if ((rc = upload_mask(h, mask, &dmask))) return rc;
+  if (!n->d_lw && (rc = dalloc(h, &n->d_lw, (size_t)G * maxT))) return rc;
+  std::vector<float> img((size_t)cnt * n->rowlen), col(cnt);
+  std::vector<int> len(G, 0);
+  for (int g = 0; g < G; ++g) {
+    if (mask && !mask[g]) continue;
+    len[g] = cnt;
+    std::fill(img.begin(), img.end(), 0.f);
+    for (int i = 0; i < cnt; ++i) memcpy(&img[(size_t)i * n->rowlen], x + ((size_t)g * cnt + i) * S, S * sizeof(float));
+    HIPCHK(hipMemcpy(n->d_traj + (size_t)g * maxT * n->rowlen, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(n->d_tgt + (size_t)g * maxT, y + (size_t)g * cnt, (size_t)cnt * 4, hipMemcpyHostToDevice));
+    for (int i = 0; i < cnt; ++i) col[i] = lw ? lw[(size_t)g * cnt + i] : 1.f;
+    HIPCHK(hipMemcpy(n->d_lw + (size_t)g * maxT, col.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemcpyAsync(n->d_len, len.data(), G * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  n->P.mask = dmask;
+  n->P.lw = lw ? n->d_lw : nullptr;
+  n->P.generic = h->force_generic ? 1 : 0;
+  n->P.fuse = 0;
+  n->P.sgate = h->gates_on ? h->d_sgate : nullptr;
+  n->P.agate = h->gates_on ? h->d_agate : nullptr;
+  n->P.sa = h->net[0].st;
+  n->P.sv = h->net[1].st;
+  const int chunks = (cnt + DDRL_MB - 1) / DDRL_MB;
+  for (int it = 0; it < iters; ++it) {
+    n->P.gm = next_draw(h, 1);
+    HIPCHK(nfac_grad_launch(&n->P, 0, chunks, it, it == iters - 1, h->stream));
+    HIPCHK(nfac_apply_launch(&n->P, 0, it, it == iters - 1, h->stream));
+  }
+  if (iters > 0) HIPCHK(nfac_finish_launch(&n->P, iters, 0, h->stream));      // Solver::iter += iters (the critic's solver only)
+  n->P.lw = nullptr;
+  HIPCHK(hipStreamSynchronize(h->stream));       // len / mask were read asynchronously
+  return DDRL_OK;
 }
 
 extern "C" int ddrl_nfac_last(ddrl_pop_t *h, float *deltas, int32_t *n_pos, float *critic_loss) {

@@ -284,6 +284,7 @@ struct NfacParams {
   float *gpart_a, *gpart_v;       // [G x maxchunks x stride] per net; pads are zero and stay zero
   float *loss_part;               // [G x maxchunks]
   float *loss_out;                // [G]
+  const float *lw;                // [G x maxT] label weights of ddrl_nfac_learn_batch_lw (MLP::learn_batch_lw, EuclideanWSLoss), or null
 };
 
 

@@ -186,6 +186,7 @@ SYMBOLS = [
     ("ddrl_nfac_max_trajectory", _i, [_vp]),
     ("ddrl_nfac_update", _i, [_vp, _vp]),
     ("ddrl_nfac_last", _i, [_vp, _vp, _vp, _vp]),
+    ("ddrl_nfac_learn_batch_lw", _i, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     ("ddrl_cmaes_create", _i, [_i, _vp, _vp, C.c_long, _i, _i, C.POINTER(_vp)]),
     ("ddrl_cmaes_destroy", _i, [_vp]),
     ("ddrl_cmaes_sample", _i, [_vp]),

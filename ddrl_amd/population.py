@@ -385,6 +385,15 @@ class NfacPopulation(Population):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
         _l.check(self.L.ddrl_nfac_update(self.h, _p(m)))
 
+    # MLP::learn_batch_lw (learn_batch with lw = None) on every (masked) agent's critic: iters full-batch Adam steps
+    def learn_batch_lw(self, x, y, lw=None, iters=1, mask=None):
+        x = np.ascontiguousarray(x, np.float32).reshape(self.G, -1, self.S)
+        n = x.shape[1]
+        y = np.ascontiguousarray(y, np.float32).reshape(self.G, n)
+        w = None if lw is None else np.ascontiguousarray(lw, np.float32).reshape(self.G, n)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.G)
+        _l.check(self.L.ddrl_nfac_learn_batch_lw(self.h, _p(x), _p(y), _p(w), n, int(iters), _p(m)))
+
     def last(self):
         deltas = np.empty((self.G, self.maxT), np.float32)
         n = np.empty(self.G, np.int32)

@@ -379,6 +379,15 @@ int ddrl_nfac_max_trajectory(ddrl_pop_t *h);
  * steps, then trajectory.clear() and ewc_decay_update().  The batch is the whole trajectory
  * (increase_batchsize, MLP.hpp:403-435): any length up to max_trajectory. */
 int ddrl_nfac_update(ddrl_pop_t *h, const uint8_t *mask);
+/* MLP::learn_batch_lw (common/include/nn/MLP.hpp:487-506; learn_batch, :468-485, with lw == NULL) on the critic (vnn) of every
+ * agent with mask[g] != 0: `iters` full-batch Adam steps on n rows x [G x n x S] -> y [G x n], each row's loss and
+ * gradient scaled by its label weight lw [G x n]: loss = sum_i lw_i (v(x_i) - y_i)^2 / (2 n), d v_i = lw_i (v(x_i) - y_i) / n
+ * (the fork's EuclideanWSLoss, MLP.hpp:958-965, is not in the tree: this is the form that reproduces the behaviour its tests pin,
+ * CaffeUtest.cpp:153-244 -- the fit goes to the weighted mean of the labels, rows of weight 0 are ignored -- and is otherwise
+ * parity unpinned).  EWC terms as in the reference's explicit loop when EWC is live.  The rows pass through the agents'
+ * trajectory buffers: 1 <= n <= max_trajectory, and agents holding gathered transitions are refused (DDRL_ESTATE).
+ * Not together with vnn_from_scratch. */
+int ddrl_nfac_learn_batch_lw(ddrl_pop_t *h, const float *x, const float *y, const float *lw, int n, int iters, const uint8_t *mask);
 /* diagnostics of the last update: advantages [G x max_trajectory] (row-padded), n = number of
  * positively advantaged transitions [G], last critic loss [G] */
 int ddrl_nfac_last(ddrl_pop_t *h, float *deltas, int32_t *n_pos, float *critic_loss);

@@ -444,6 +444,38 @@ double ora_mlp_learn_batch(ora_mlp *n, const double *x, const double *y, int B, 
   return loss;
 }
 
+/* MLP::learn_batch_lw (MLP.hpp:487-506): learn_batch with setWeightedSampleVector(&lw).  The fork's EuclideanWSLoss layer
+ * (MLP.hpp:958-965) is not in the tree; restated as the per-sample weighted Euclidean loss, loss = sum w_i (yhat_i - y_i)^2 / (2B),
+ * d yhat_i = w_i (yhat_i - y_i) / B, which is what the reference's own tests of it pin (CaffeUtest.cpp:153-244: the fit goes to
+ * the weighted mean of the labels, zero-weight rows are ignored).  Beyond that behaviour: parity unpinned. */
+double ora_mlp_learn_batch_lw(ora_mlp *n, const double *x, const double *y, const double *lw, int B, int iters) {
+  int dl = n->d[n->L];
+  double *out = (double *)malloc(sizeof(double) * B * dl);
+  double *dout = (double *)malloc(sizeof(double) * B * dl);
+  double loss = 0.;
+  for (int it = 0; it < iters; ++it) {
+    ora_mlp_zero_grad(n);
+    ora_mlp_forward(n, x, B, out);
+    loss = 0.;
+    for (int i = 0; i < B * dl; ++i) {
+      double df = out[i] - y[i];
+      double w = lw[i / dl];
+      loss += w * df * df;
+      dout[i] = w * df / (double)B;
+    }
+    loss = loss / (double)B / 2.;
+    ora_mlp_backward(n, dout, B, NULL);
+    if (ora_mlp_ewc_active(n) >= 0) {
+      ora_mlp_update_fisher(n, (double)B);
+      ora_mlp_regularize(n);
+    }
+    ora_mlp_apply_update(n);
+    n->iter += 1;
+  }
+  free(out); free(dout);
+  return loss;
+}
+
 /* MLP::soft_update (MLP.hpp:437-452): to = tau*from + (1.f - tau)*to  (caffe_cpu_axpby) */
 void ora_mlp_soft_update(ora_mlp *to, const ora_mlp *from, double tau) {
   double b = (1.f - tau);

@@ -69,6 +69,7 @@ void   ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din);
 void   ora_mlp_zero_grad(ora_mlp *n);
 void   ora_mlp_apply_update(ora_mlp *n);            /* Solver::ApplyUpdate (no ++iter) */
 double ora_mlp_learn_batch(ora_mlp *n, const double *x, const double *y, int B, int iters);
+double ora_mlp_learn_batch_lw(ora_mlp *n, const double *x, const double *y, const double *lw, int B, int iters);
 void   ora_mlp_soft_update(ora_mlp *to, const ora_mlp *from, double tau);
 /* EWC (DODevMLP.hpp:604-758) */
 void   ora_mlp_ewc_config(ora_mlp *n, double ewc, double ewc_decay, double fisher_beta, int best_method);

@@ -97,6 +97,8 @@ def lib():
     L.ora_mlp_apply_update.argtypes = [vp]
     L.ora_mlp_learn_batch.restype = C.c_double
     L.ora_mlp_learn_batch.argtypes = [vp, _dp, _dp, C.c_int, C.c_int]
+    L.ora_mlp_learn_batch_lw.restype = C.c_double
+    L.ora_mlp_learn_batch_lw.argtypes = [vp, _dp, _dp, _dp, C.c_int, C.c_int]
     L.ora_mlp_soft_update.argtypes = [vp, vp, C.c_double]
     L.ora_mlp_ewc_config.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int]
     L.ora_mlp_update_fisher.argtypes = [vp, C.c_double]
@@ -271,6 +273,13 @@ class Mlp:
 
     def iter(self):
         return lib().ora_mlp_iter(self.h)
+
+    def learn_batch_lw(self, x, y, lw, iters=1):
+        """MLP::learn_batch_lw (MLP.hpp:487-506)"""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.dims[0])
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(x.shape[0], self.dims[-1])
+        lw = np.ascontiguousarray(lw, dtype=np.float64).reshape(x.shape[0])
+        return lib().ora_mlp_learn_batch_lw(self.h, x, y, lw, x.shape[0], iters)
 
     def learn_batch(self, x, y, iters=1):
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.dims[0])
