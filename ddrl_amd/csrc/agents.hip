@@ -219,11 +219,9 @@ static int read_devnn(ddrl_agents *h, DdrlIni &ini, const char *ini_path, uint64
   for (long c : d.ac_control) if (c < 0 || c >= h->A) return ddrl_fail(DDRL_EINVAL, "devnn.ac_control %ld outside 0..%d", c, h->A - 1);
   if (d.heuristic == 2 && d.informed) return ddrl_fail(DDRL_EINVAL, "informed_sensorimotor_space is not implemented with proba action");   // :161-169
   if (d.heuristic == 2 && d.reset_learning_algo) return ddrl_fail(DDRL_EINVAL, "when sould I reset ? I'm progressive");                    // :197-200
-  if (d.heuristic == 2 && h->algo == 3) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the TD3 update");
   if (h->algo == 1 && d.reset_learning_algo) return ddrl_fail(DDRL_EINVAL, "NFAC cannot reset anything with DODevMLP");   // OfflineCaclaAg.hpp:199-203
   if (h->algo == 2) return ddrl_fail(DDRL_EINVAL, "the developmental schedule is not supported for CMA-ES agents");
   if (d.st_bern || d.ac_bern) {
-    if (h->algo == 3) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the TD3 update");
     int rc = ddrl_pop_set_gate_mode(h->pop, d.st_bern ? 1 : 0, d.st_scale ? 1 : 0, d.ac_bern ? 1 : 0, d.ac_scale ? 1 : 0,
                                     (uint32_t)(seed * 2246822519ull + 374761393u));
     if (rc) return rc;

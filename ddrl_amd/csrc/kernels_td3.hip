@@ -78,6 +78,31 @@ extern "C" hipError_t td3_prep_launch(const uint64_t *seed, uint32_t *count, con
   return hipGetLastError();
 }
 
+// Bernoulli gates (DODevMLP.hpp:276-304, probabilist = 0): every Developmental layer instance draws its own mask per forward
+// pass, and TD3 has two more nets with such layers than DDPG (qnn2, qnn_target2).  The two critics of a pair read the same
+// input tile, so for the second one -- and for the first critic's pass of the actor phase, after the second critic has had
+// the tile -- the critic's input tile is built again from the replay rows with that net's sites (uniform branch: the
+// deterministic gates are the same for every instance and never come here).
+__device__ __forceinline__ void td3_regate_xc(const DdpgParams &P, int S, int A, int ldxc, int agent, const int *__restrict__ idx, int B,
+                                              int head, bool next, const LdsMap &M, int tid, int site_s, int site_a) {
+  const float *rep = P.rep + (size_t)agent * P.cap * P.rowlen;
+  const float *sg = P.sgate ? P.sgate + (size_t)agent * S : nullptr, *ag = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  const GateMode &gm = P.gm;
+  const int ncol = next ? S : S + A;
+  for (int e = tid; e < DDRL_MB * ncol; e += DDRL_NTHREADS) {
+    const int row = e / ncol, col = e - row * ncol;
+    float v = 0.f;
+    if (row < B) {
+      int phys = head + idx[row];
+      if (phys >= P.cap) phys -= P.cap;
+      v = rep[(size_t)phys * P.rowlen + (next ? S + A + col : col)];
+      if (col < S) { if (sg) v *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, site_s, row, col); }
+      else if (ag) v *= ddrl_gate_factor(ag[col - S], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, site_a, row, col - S);
+    }
+    M.xc[row * ldxc + col] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 template <class NA, class NQ, bool EWC_A, bool EWC_Q>
 __global__ void __launch_bounds__(DDRL_NTHREADS, DDRL_NTHREADS / 128)   // two workgroups per CU
@@ -112,17 +137,29 @@ td3_update_kernel(const DdpgParams P) {
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);
   __syncthreads();
   fwd_net(na, na.L(), w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);
+  const bool bern = (P.sgate || P.agate) && (P.gm.st_bern || P.gm.ac_bern);     // uniform
   for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
     const int row = e / A, col = e - row * A;
     float a = M.topa[row * lda + col];
-    if (agate) a *= agate[col];                            // the actor's output gate
+    const GateMode &gm = P.gm;
+    if (agate) a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_ACTOR_T_OUT, row, col);   // the actor's output gate
     if (row < B) a = fminf(fmaxf(a + noise[row * A + col], -1.f), 1.f);
-    if (agate) a *= agate[col];                            // the critics' action-input gate
+    if (bern) M.topa[row * lda + col] = a;                 // a' itself: the second target critic gates it with its own mask
+    if (agate) a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_CRITIC_T_A, row, col);    // the critic's action-input gate
     M.xc[row * ldxc + S + col] = a;
   }
   __syncthreads();
   fwd_net(nq, nq.L(), w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
   if (tid < DDRL_MB) q1n[tid] = M.topq[tid * ldq];
+  if (bern) {
+    td3_regate_xc(P, S, A, ldxc, agent, idx, B, head, true, M, tid, GS_CRITIC2_T_S, 0);
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+      const int row = e / A, col = e - row * A;
+      float a = M.topa[row * lda + col];
+      if (agate) a *= ddrl_gate_factor(agate[col], P.gm.ac_bern, P.gm.ac_scale, P.gm.seed, P.gm.draw, agent, GS_CRITIC2_T_A, row, col);
+      M.xc[row * ldxc + S + col] = a;
+    }
+  }
   __syncthreads();
   fwd_net(nq, nq.L(), w_q2t, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
 
@@ -152,6 +189,10 @@ td3_update_kernel(const DdpgParams P) {
     const LdsMap M = ddpg_carve(lds + z1, na.L(), nq.L(), P.ldh, ldxc, ldxa, ldq, lda);
     float *park = ParkOf<NA, NQ>::value ? M.topq : nullptr;
     const float *wk = (k == 0 ? P.sq.w : P.sq2.w) + (size_t)agent * nq.stride();
+    if (k == 1 && bern) {                                  // qnn2's own masks over (s, a)
+      td3_regate_xc(P, S, A, ldxc, agent, P.idx + (size_t)agent * B, B, head, false, M, tid, GS_CRITIC2_S, GS_CRITIC2_A_REPLAY);
+      __syncthreads();
+    }
     fwd_net(nq, nq.L(), wk, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
     if (tid < DDRL_MB) {
       // EuclideanLoss: loss = sum (q - y)^2 / (2B), dq = (q - y) / B
@@ -181,13 +222,16 @@ td3_update_kernel(const DdpgParams P) {
     const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_q = P.sq.w + (size_t)agent * nq.stride();
     float *park = ParkOf<NA, NQ>::value ? M.topq : nullptr;
     fwd_net(na, na.L(), w_a, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);       // pi = ann(s)
+    if (bern) td3_regate_xc(P, S, A, ldxc, agent, P.idx + (size_t)agent * B, B, head, false, M, tid, GS_CRITIC_S, GS_CRITIC_A_REPLAY);   // the first critic's state masks again
+    if (bern) __syncthreads();                                                               // (its action columns are rewritten below)
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, col = e - row * A;
       float a = M.topa[row * lda + col];
       if (agate) {
-        a *= agate[col];
+        const GateMode &gm = P.gm;
+        a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_ACTOR_OUT, row, col);
         M.topa[row * lda + col] = a;
-        a *= agate[col];
+        a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_CRITIC_A, row, col);
       }
       M.xc[row * ldxc + S + col] = a;
     }
@@ -199,10 +243,16 @@ td3_update_kernel(const DdpgParams P) {
       float *topa = M.topa;
       const int out_act = na.out_act();
       float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
+      const DdpgParams *Pg = &P;
       auto store = [=](int row, int h, float diff) {       // ShareDiff (:358): no inverting gradients in this agent
         float out = topa[row * lda + h];
-        const float gt = agate ? agate[h] : 1.f;
-        diff *= gt;
+        float gin = 1.f, gt = 1.f;                         // the masks of the forward passes these gradients belong to
+        if (agate) {
+          const GateMode &gm = Pg->gm;
+          gin = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_CRITIC_A, row, h);
+          gt = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_ACTOR_OUT, row, h);
+        }
+        diff *= gin;
         if (dact_out && row < B) dact_out[row * A + h] = diff;
         diff *= gt;
         if (gt != 0.f) out /= gt;

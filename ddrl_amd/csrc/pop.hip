@@ -794,7 +794,9 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
   P.mask = dmask;
   P.sgate = h->gates_on ? h->d_sgate : nullptr;
   P.agate = h->gates_on ? h->d_agate : nullptr;
-  if (h->gates_on && bernoulli_gates(h)) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the TD3 update");
+  if (h->gates_on && bernoulli_gates(h) && (h->wide || P.maxchunks > 1 || h->force_chunked))
+    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are served by the one-tile TD3 update only (minibatches <= 64 rows, layers <= 128 wide)");
+  P.gm = next_draw(h, 1);
   P.sa = h->net[0].st; P.sq = h->net[1].st; P.sq2 = h->net[2].st;
   P.actor_step = actor_step ? h->d_astep : nullptr;
   P.nupd = 1;
@@ -923,8 +925,8 @@ extern "C" int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *act
 // *_scale divides a passed value by w.  seed starts the counter-based draw stream again.
 extern "C" int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
-  if ((h->wide || h->P.maxchunks > 1 || h->nnets == 3) && (st_bernoulli || ac_bernoulli))
-    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are served by the one-tile DDPG and the NFAC update paths only");
+  if ((h->wide || h->P.maxchunks > 1) && (st_bernoulli || ac_bernoulli))
+    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are served by the one-tile DDPG / TD3 and the NFAC update paths only (minibatches <= 64 rows, layers <= 128 wide)");
   h->gm.st_bern = st_bernoulli ? 1 : 0; h->gm.st_scale = st_scale ? 1 : 0;
   h->gm.ac_bern = ac_bernoulli ? 1 : 0; h->gm.ac_scale = ac_scale ? 1 : 0;
   h->gm.seed = seed; h->gm.draw = 0;

@@ -93,7 +93,8 @@ __host__ __device__ constexpr int ddrl_wsize(int N, int kp) { return ddrl_roundu
 //   pass rates the reference tests state.
 struct GateMode { int st_bern, st_scale, ac_bern, ac_scale; unsigned seed, draw; };
 enum { GS_ACTOR_T_S = 0, GS_CRITIC_T_S, GS_ACTOR_T_OUT, GS_CRITIC_T_A, GS_CRITIC_S, GS_CRITIC_A_REPLAY, GS_ACTOR_S, GS_ACTOR_OUT,
-       GS_CRITIC_A, GS_INFER_S, GS_INFER_OUT, GS_BATCH_S, GS_BATCH_A, GS_NFAC_V_S, GS_NFAC_V_S2, GS_NFAC_A_S, GS_NFAC_A_OUT };
+       GS_CRITIC_A, GS_INFER_S, GS_INFER_OUT, GS_BATCH_S, GS_BATCH_A, GS_NFAC_V_S, GS_NFAC_V_S2, GS_NFAC_A_S, GS_NFAC_A_OUT,
+       GS_CRITIC2_T_S, GS_CRITIC2_T_A, GS_CRITIC2_S, GS_CRITIC2_A_REPLAY };      // TD3's second critic and its target: layer instances of their own
 __host__ __device__ inline unsigned ddrl_mix32(unsigned x) {
   x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
   return x;

@@ -280,3 +280,51 @@ def test_heuristic2_linear_ramp(tmp_path):
             f.write(ds.AGENT + text)
         with pytest.raises(ddrl_amd.DdrlError, match=msg):
             ddrl_amd.DdpgAgents(p, G, S, A)
+
+
+@pytest.mark.parametrize("scale", [0, 1])
+def test_td3_update_given_masks(ora, scale):
+    """The one-tile TD3 update with Bernoulli gates against the oracle fed the device's per-row masks: TD3's second critic and
+    its target have Developmental layers of their own (sites GS_CRITIC2_*), a policy step runs the first critic once more, the
+    delayed (critic-only) steps never touch the actor's layers."""
+    import test_td3_gpu as t3
+    G, S, A, B = 3, 18, 6, 64
+    C2_T_S, C2_T_A, C2_S, C2_A_REPLAY = 17, 18, 19, 20
+    pop, agents = t3.make_td3(ora, G=G, hidden_a=(100, 100), hidden_q=(100, 100), seed=9)
+    rng = np.random.RandomState(4)
+    sg = np.round(rng.uniform(0.3, 1, (G, S)), 2); sg[:, ::3] = 1.0
+    ag = np.round(rng.uniform(0.3, 1, (G, A)), 2); ag[:, 0] = 1.0
+    sg = sg.astype(np.float32).astype(np.float64); ag = ag.astype(np.float32).astype(np.float64)
+    pop.set_gates(sg, ag)
+    seed = 31
+    for upd, astep in enumerate([np.array([1, 1, 1], np.uint8), np.array([0, 1, 0], np.uint8)]):
+        pop.set_gate_mode(1, scale, 1, scale, seed=seed + upd)          # draw counter 0 for the coming update
+        idx = np.random.RandomState(50 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        noise = np.random.RandomState(60 + upd).normal(0, 0.1, (G, B, A)).astype(np.float32)
+        for g, a in enumerate(agents):
+            F = lambda wv, site: gate_factors(wv, 1, scale, seed + upd, 0, g, site, B)
+            cat = lambda s_site, a_site: np.concatenate([F(sg[g], s_site), F(ag[g], a_site)], 1)
+            a.ann_target.push_row_gates(F(sg[g], ACTOR_T_S), F(ag[g], ACTOR_T_OUT), B)
+            a.qnn_target.push_row_gates(cat(CRITIC_T_S, CRITIC_T_A), None, B)
+            a.qnn_target2.push_row_gates(cat(C2_T_S, C2_T_A), None, B)
+            a.qnn.push_row_gates(cat(CRITIC_S, CRITIC_A_REPLAY), None, B)
+            a.qnn2.push_row_gates(cat(C2_S, C2_A_REPLAY), None, B)
+            if astep[g]:
+                a.ann.push_row_gates(F(sg[g], ACTOR_S), F(ag[g], ACTOR_OUT), B)
+                a.qnn.push_row_gates(cat(CRITIC_S, CRITIC_A), None, B)
+        t3.step_and_check(pop, agents, idx, noise, astep)
+        for a in agents:
+            assert all(n.row_gates_pending() == 0 for n in a.nets)
+    # w in {0, 1}: the Bernoulli gates are the deterministic ones, bit for bit
+    res = []
+    for bern in (0, 1):
+        p, _ = t3.make_td3(ora, G=G, hidden_a=(100, 100), hidden_q=(100, 100), seed=9)
+        p.set_gates((sg > 0.6).astype(np.float64), (ag > 0.6).astype(np.float64))
+        p.set_gate_mode(bern, bern, bern, bern, seed=5)
+        for upd in range(2):
+            p.update(idx=idx, noise=noise, actor_step=np.array([1, upd, 1], np.uint8))
+        res.append([p.weights(n) for n in (0, 1, 2, 3, 4, 5)])
+        p.close()
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+    pop.close()
