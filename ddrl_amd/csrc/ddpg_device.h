@@ -35,7 +35,7 @@ struct LdsMap {
 // reward / goal into rv / dn.
 __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, int ldxc, int ldxa, int agent,
                                             const int *__restrict__ idx, int B, int head, bool next,
-                                            const LdsMap &M, int tid, int u = 0) {
+                                            const LdsMap &M, int tid, int u = 0, int row_base = 0) {      // row_base: the tile's first row in the minibatch (chunked updates: the masks are drawn per minibatch row)
   // DDRL_NTHREADS / 64 threads per row, each with its own column residue: a thread reads idx[row] once
   // and its row loads are independent of each other, so the whole gather costs two memory round trips
   // (index, then row) instead of two per element
@@ -64,11 +64,11 @@ __device__ __forceinline__ void gather_tile(const DdpgParams &P, int S, int A, i
       const GateMode &gm = P.gm;
       const unsigned draw = gm.draw + (unsigned)u;
       if (sg && col < S) {
-        vc *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_CRITIC_T_S : GS_CRITIC_S, row, col);
-        va *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_ACTOR_T_S : GS_ACTOR_S, row, col);
+        vc *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_CRITIC_T_S : GS_CRITIC_S, row_base + row, col);
+        va *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, draw, agent, next ? GS_ACTOR_T_S : GS_ACTOR_S, row_base + row, col);
       }
       if (ag && col >= S && col < S + A)
-        vc *= ddrl_gate_factor(ag[col - S], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_CRITIC_A_REPLAY, row, col - S);
+        vc *= ddrl_gate_factor(ag[col - S], gm.ac_bern, gm.ac_scale, gm.seed, draw, agent, GS_CRITIC_A_REPLAY, row_base + row, col - S);
     }
     M.xc[row * ldxc + col] = vc;
     if (col < ldxa) M.xa[row * ldxa + col] = col < S ? va : 0.f;

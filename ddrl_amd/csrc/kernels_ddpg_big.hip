@@ -36,14 +36,17 @@ ddpg_chunk_kernel(const DdpgParams P) {
   const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
   const float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
   const float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
-  auto actions_to_critic = [&]() {     // actor output (gated) into the critic's action columns (gated again)
+  // actor output (gated) into the critic's action columns (gated again).  Bernoulli gates (DDPG only here): each layer instance's
+  // mask is drawn per MINIBATCH row (row0 + row), the same masks the one-tile kernel would draw
+  auto actions_to_critic = [&]() {
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, col = e - row * A;
       float a = M.topa[row * lda + col];
       if (agate) {
-        a *= agate[col];
+        const GateMode &gm = P.gm;
+        a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, PHASE == 0 ? GS_ACTOR_T_OUT : GS_ACTOR_OUT, row0 + row, col);
         M.topa[row * lda + col] = a;
-        a *= agate[col];
+        a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, PHASE == 0 ? GS_CRITIC_T_A : GS_CRITIC_A, row0 + row, col);
       }
       M.xc[row * ldxc + S + col] = a;
     }
@@ -54,7 +57,7 @@ ddpg_chunk_kernel(const DdpgParams P) {
 
   if (PHASE == 0) {
     if (P.nstep > 0) nstep_horizon(P, S, A, agent, idx, nrows, len, head, gamma, M, tid);
-    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, true, M, tid);
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, true, M, tid, 0, row0);
     __syncthreads();
     fwd_net(na, na.L(), w_at, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);    // a' = ann_target(s')
     if (TD3) {
@@ -76,7 +79,7 @@ ddpg_chunk_kernel(const DdpgParams P) {
       __syncthreads();
       fwd_net(nq, nq.L(), P.sq2.wt + (size_t)agent * nq.stride(), M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
     }
-    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid, 0, row0);
     int trow;
     if (gather_owns_row(tid, trow)) {
       const float qn = TD3 ? fminf(M.nrew[trow], M.topq[trow * ldq]) : M.topq[trow * ldq];
@@ -101,7 +104,7 @@ ddpg_chunk_kernel(const DdpgParams P) {
       bwd_net<DW_STORE, false>(nq, wk, unused, gout, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, 0, 0, none, wave, lane, tid);
     }
   } else {
-    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid, 0, row0);
     __syncthreads();
     fwd_net(na, na.L(), w_a, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, wave, lane);     // pi = ann(s)
     actions_to_critic();
@@ -112,10 +115,16 @@ ddpg_chunk_kernel(const DdpgParams P) {
       float *topa = M.topa;
       const int inverting = P.inverting, out_act = na.out_act();
       float *dact_out = P.dact_out ? P.dact_out + ((size_t)agent * B + row0) * A : nullptr;
+      const DdpgParams *Pg = &P;
       auto store = [=](int row, int h, float diff) {
         float out = topa[row * lda + h];
-        const float gt = agate ? agate[h] : 1.f;
-        diff *= gt;
+        float gin = 1.f, gt = 1.f;                                          // the masks of the forward passes these gradients belong to
+        if (agate) {
+          const GateMode &gm = Pg->gm;
+          gin = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_CRITIC_A, row0 + row, h);
+          gt = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_ACTOR_OUT, row0 + row, h);
+        }
+        diff *= gin;
         if (inverting) {                                                   // :432-450
           if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
           else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;

@@ -229,10 +229,52 @@ def test_nfac_update_given_masks(ora):
 
 def test_refused_where_not_served(ora):
     import ddrl_amd
-    pop, _ = make_pair(ora, G=2, B=128, hidden_a=(100, 100), hidden_q=(100, 100), n_replay=300)       # two minibatch tiles
-    with pytest.raises(ddrl_amd.DdrlError, match="one-tile"):
+    pop, _ = make_pair(ora, G=2, B=64, hidden_a=(200, 100), hidden_q=(100, 100), n_replay=300)       # a layer wider than 128: layer-by-layer launches
+    with pytest.raises(ddrl_amd.DdrlError, match="128 wide"):
         pop.set_gate_mode(1, 0, 1, 0, seed=1)
     pop.set_gate_mode(0, 0, 0, 0)
+    pop.close()
+    import test_td3_gpu as t3
+    pop, _ = t3.make_td3(ora, G=2, B=128, hidden_a=(64, 32), hidden_q=(48, 40), n_replay=300)        # TD3 over two minibatch tiles
+    with pytest.raises(ddrl_amd.DdrlError, match="one-tile TD3"):
+        pop.set_gate_mode(1, 0, 1, 0, seed=1)
+    pop.close()
+
+
+@pytest.mark.parametrize("B,scale", [(128, 1), (160, 0)])
+def test_ddpg_chunked_update_given_masks(ora, B, scale):
+    """Minibatches of more than 64 rows (chunk + apply kernels, kernels_ddpg_big.hip) with Bernoulli gates: the masks are drawn per
+    MINIBATCH row, so the oracle fed the generator's masks for rows 0 .. B-1 must agree whatever the chunking."""
+    G, S, A = 2, 18, 6
+    pop, agents = make_pair(ora, G=G, B=B, hidden_a=(64, 32), hidden_q=(48, 40), wscale=0.1, seed=11)
+    rng = np.random.RandomState(6)
+    sg = np.round(rng.uniform(0.3, 1, (G, S)), 2); sg[:, ::3] = 1.0
+    ag = np.round(rng.uniform(0.3, 1, (G, A)), 2); ag[:, 0] = 1.0
+    sg = sg.astype(np.float32).astype(np.float64); ag = ag.astype(np.float32).astype(np.float64)
+    pop.set_gates(sg, ag)
+    seed = 91
+    for upd in range(2):
+        pop.set_gate_mode(1, scale, 1, scale, seed=seed + upd)
+        ws_prev = [pop.weights(n) for n in range(4)]
+        idx = np.random.RandomState(15 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        for g, a in enumerate(agents):
+            F = lambda wv, site: gate_factors(wv, 1, scale, seed + upd, 0, g, site, B)
+            a.ann_target.push_row_gates(F(sg[g], ACTOR_T_S), F(ag[g], ACTOR_T_OUT), B)
+            a.qnn_target.push_row_gates(np.concatenate([F(sg[g], CRITIC_T_S), F(ag[g], CRITIC_T_A)], 1), None, B)
+            a.qnn.push_row_gates(np.concatenate([F(sg[g], CRITIC_S), F(ag[g], CRITIC_A_REPLAY)], 1), None, B)
+            a.qnn.push_row_gates(np.concatenate([F(sg[g], CRITIC_S), F(ag[g], CRITIC_A)], 1), None, B)
+            a.ann.push_row_gates(F(sg[g], ACTOR_S), F(ag[g], ACTOR_OUT), B)
+        pop.update(idx)
+        last = pop.last()
+        for g, a in enumerate(agents):
+            loss, _ = a.update(idx[g])
+            assert all(n.row_gates_pending() == 0 for n in (a.ann, a.qnn, a.ann_target, a.qnn_target))
+            qt, dact = a.last()
+            assert rel_err(last["q_targets"][g], qt) <= TOL
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            assert rel_err(last["dact"][g], dact) <= TOL
+        hyper = (np.array([a.cfg.alpha_a for a in agents]), np.array([a.cfg.alpha_v for a in agents]))
+        check_step(pop, agents, ws_prev, hyper, 0, TOL)
     pop.close()
 
 
