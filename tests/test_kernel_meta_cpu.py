@@ -24,3 +24,16 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers():
         assert any(want in k for k in meta), want
     bad = {k: m for k, m in meta.items() if m.get("scratch", 0) != 0 or m.get("vgpr_spill", 0) != 0}
     assert not bad, "kernels with scratch memory / spilled vector registers: %r" % bad
+
+
+@pytest.mark.skipif(not km.tools_present() or not os.path.exists(SO), reason="ROCm LLVM tools or the built library are absent")
+def test_static_schedules_of_the_judged_kernel_are_unrolled():
+    """The compile-time-shape passes are `#pragma unroll` loops that LLVM unrolls only under -mllvm -pragma-unroll-threshold
+    (csrc/Makefile); -Wno-pass-failed hides the warning when it does not (round 2 lost a change to exactly that).  Held here
+    instead: the mid-size instantiations of the default multi-update kernel must carry their passes' MFMAs as straight-line
+    code -- an update issues 2 912 per wave, of which the four waves' paths share most; a rolled schedule has a few hundred."""
+    counts = km.kernel_mfma_counts(SO, "ddpg_update_loop_kernel")
+    mid = {k: n for k, n in counts.items() if "Li18ELi100ELi100ELi6" in k}
+    assert len(mid) == 3, sorted(counts)
+    for k, n in mid.items():
+        assert n >= 2000, (k, n)

@@ -14,7 +14,7 @@ TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
 def tools_present():
-    return all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))
+    return all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf", "llvm-objdump"))
 
 
 def kernel_meta(so_path):
@@ -52,6 +52,41 @@ def kernel_meta(so_path):
                     if "name" in cur:
                         out[cur.pop("name")] = cur
                     cur = {}
+    return out
+
+
+def kernel_mfma_counts(so_path, name_filter):
+    """-> {kernel name: number of v_mfma instructions in its code} for the kernels whose name contains name_filter
+    (llvm-objdump -d of the gfx950 code objects).  A static schedule that LLVM left ROLLED shows up as a fraction of the
+    fully unrolled count (and usually as scratch memory, which tests/test_kernel_meta_cpu.py checks separately)."""
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so_path, os.path.join(d, "unused")],
+                       check=True, capture_output=True)
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for i, s in enumerate(starts):
+            chunk = blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)]
+            if name_filter.encode() not in chunk:
+                continue
+            part, co = os.path.join(d, "bundle%d.bin" % i), os.path.join(d, "dev%d.co" % i)
+            with open(part, "wb") as f:
+                f.write(chunk)
+            subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                            "--targets=" + TARGET, "--output=" + co], check=True, capture_output=True)
+            if os.path.getsize(co) == 0:
+                continue
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+            cur = None
+            for ln in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+                if m:
+                    cur = m.group(1) if name_filter in m.group(1) else None
+                    if cur:
+                        out[cur] = 0
+                elif cur and "v_mfma" in ln:
+                    out[cur] += 1
     return out
 
 
