@@ -147,6 +147,32 @@ __device__ __forceinline__ void gather_store(const DdpgParams &P, int S, int A, 
   if (!next && q == 0) { M.rv[row] = g.r; M.dn[row] = g.dn; }
 }
 
+// Bernoulli gates (DODevMLP.hpp:276-304, probabilist = 0): every Developmental layer instance draws its own mask per forward
+// pass, and TD3 has two more nets with such layers than DDPG (qnn2, qnn_target2).  The two critics of a pair read the same
+// input tile, so for the second one -- and for the first critic's pass of the actor phase, after the second critic has had
+// the tile -- the critic's input tile is built again from the replay rows with that net's sites (uniform branch: the
+// deterministic gates are the same for every instance and never come here).
+__device__ __forceinline__ void td3_regate_xc(const DdpgParams &P, int S, int A, int ldxc, int agent, const int *__restrict__ idx, int B,
+                                              int head, bool next, const LdsMap &M, int tid, int site_s, int site_a, int row_base = 0) {
+  const float *rep = P.rep + (size_t)agent * P.cap * P.rowlen;
+  const float *sg = P.sgate ? P.sgate + (size_t)agent * S : nullptr, *ag = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  const GateMode &gm = P.gm;
+  const int ncol = next ? S : S + A;
+  for (int e = tid; e < DDRL_MB * ncol; e += DDRL_NTHREADS) {
+    const int row = e / ncol, col = e - row * ncol;
+    float v = 0.f;
+    if (row < B) {
+      int phys = head + idx[row];
+      if (phys >= P.cap) phys -= P.cap;
+      v = rep[(size_t)phys * P.rowlen + (next ? S + A + col : col)];
+      if (col < S) { if (sg) v *= ddrl_gate_factor(sg[col], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, site_s, row_base + row, col); }
+      else if (ag) v *= ddrl_gate_factor(ag[col - S], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, site_a, row_base + row, col - S);
+    }
+    M.xc[row * ldxc + col] = v;
+  }
+}
+
+
 template <bool EWC>
 __device__ __forceinline__ OptCtx make_opt(const DdpgParams &P, const NetState &s, int stride,
                                            int agent, float tau, float omtau, float nsample, int u = 0) {

@@ -54,6 +54,7 @@ ddpg_chunk_kernel(const DdpgParams P) {
   };
   auto none = [](int, int, float) {};
   OptCtx unused = {};
+  const bool bern = (P.sgate || P.agate) && (P.gm.st_bern || P.gm.ac_bern);     // uniform
 
   if (PHASE == 0) {
     if (P.nstep > 0) nstep_horizon(P, S, A, agent, idx, nrows, len, head, gamma, M, tid);
@@ -66,9 +67,11 @@ ddpg_chunk_kernel(const DdpgParams P) {
       for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
         const int row = e / A, col = e - row * A;
         float a = M.topa[row * lda + col];
-        if (agate) a *= agate[col];
+        const GateMode &gm = P.gm;
+        if (agate) a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_ACTOR_T_OUT, row0 + row, col);
         if (row < nrows) a = fminf(fmaxf(a + noise[row * A + col], -1.f), 1.f);
-        if (agate) a *= agate[col];
+        if (bern) M.topa[row * lda + col] = a;              // a' itself: the second target critic gates it with its own mask
+        if (agate) a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_CRITIC_T_A, row0 + row, col);
         M.xc[row * ldxc + S + col] = a;
       }
       __syncthreads();
@@ -76,6 +79,15 @@ ddpg_chunk_kernel(const DdpgParams P) {
     fwd_net(nq, nq.L(), w_qt, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);    // q' = qnn_target(s', a')
     if (TD3) {                                                                              // Q2'(s', a') (:314)
       if (tid < DDRL_MB) M.nrew[tid] = M.topq[tid * ldq];
+      if (bern) {                                           // qnn_target2's own layer instances (kernels_td3.hip)
+        td3_regate_xc(P, S, A, ldxc, agent, idx, nrows, head, true, M, tid, GS_CRITIC2_T_S, 0, row0);
+        for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+          const int row = e / A, col = e - row * A;
+          float a = M.topa[row * lda + col];
+          if (agate) a *= ddrl_gate_factor(agate[col], P.gm.ac_bern, P.gm.ac_scale, P.gm.seed, P.gm.draw, agent, GS_CRITIC2_T_A, row0 + row, col);
+          M.xc[row * ldxc + S + col] = a;
+        }
+      }
       __syncthreads();
       fwd_net(nq, nq.L(), P.sq2.wt + (size_t)agent * nq.stride(), M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
     }
@@ -91,6 +103,10 @@ ddpg_chunk_kernel(const DdpgParams P) {
 #pragma unroll
     for (int k = 0; k < (TD3 ? 2 : 1); ++k) {              // qnn (and qnn2, TD3Ag.hpp:329-330) learn the same targets
       const float *wk = k == 0 ? w_q : P.sq2.w + (size_t)agent * nq.stride();
+      if (TD3 && k == 1 && bern) {                           // qnn2's own masks over (s, a)
+        td3_regate_xc(P, S, A, ldxc, agent, idx, nrows, head, false, M, tid, GS_CRITIC2_S, GS_CRITIC2_A_REPLAY, row0);
+        __syncthreads();
+      }
       fwd_net(nq, nq.L(), wk, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, wave, lane);
       if (tid < DDRL_MB) {
         const float df = tid < nrows ? M.topq[tid * ldq] - ykeep : 0.f;

@@ -293,22 +293,24 @@ wide_step_kernel(const DdpgParams P, int step, int policy) {
   const int len = P.rep_len[agent], head = P.rep_head[agent];
   const float gamma = P.gamma[agent];
   const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  const bool bern = (P.sgate || P.agate) && (P.gm.st_bern || P.gm.ac_bern);     // uniform
   if (step == 0) {                       // s' tiles for the target pass
     if (P.nstep > 0) nstep_horizon(P, S, A, agent, idx, nrows, len, head, gamma, M, tid);
-    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, true, M, tid);
-  } else if (step == 1) {                // actor output (gated) into the critic's action columns (gated again)
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, true, M, tid, 0, row0);
+  } else if (step == 1 || step == 13) {  // actor output (gated) into the critic's action columns (gated again); 1: target nets, 13: trained nets
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, col = e - row * A;
       float a = M.topa[row * lda + col];
       if (agate) {
-        a *= agate[col];
+        const GateMode &gm = P.gm;        // Bernoulli gates: each layer instance's mask per minibatch row, as in the one-tile kernel
+        a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, step == 1 ? GS_ACTOR_T_OUT : GS_ACTOR_OUT, row0 + row, col);
         M.topa[row * lda + col] = a;
-        a *= agate[col];
+        a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, step == 1 ? GS_CRITIC_T_A : GS_CRITIC_A, row0 + row, col);
       }
       M.xc[row * ldxc + S + col] = a;
     }
   } else if (step == 2) {                // [s|a] tiles + TD targets (DeepQNAg.hpp:386-405)
-    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid, 0, row0);
     int trow;
     if (gather_owns_row(tid, trow)) {
       const float qn = M.topq[trow * ldq];
@@ -343,15 +345,29 @@ wide_step_kernel(const DdpgParams P, int step, int policy) {
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, col = e - row * A;
       float a = M.topa[row * lda + col];
-      if (agate) a *= agate[col];
+      const GateMode &gm = P.gm;
+      if (agate) a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_ACTOR_T_OUT, row0 + row, col);
       if (row < nrows) a = fminf(fmaxf(a + noise[row * A + col], -1.f), 1.f);
-      if (agate) a *= agate[col];
+      if (bern) M.topa[row * lda + col] = a;            // a' itself: the second target critic gates it with its own mask
+      if (agate) a *= ddrl_gate_factor(agate[col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_CRITIC_T_A, row0 + row, col);
       M.xc[row * ldxc + S + col] = a;
     }
   } else if (step == 7) {                // TD3: Q1'(s', a') aside while the second target critic runs (:313-314)
     if (tid < DDRL_MB) M.nrew[tid] = M.topq[tid * ldq];
+    if (bern) {                          // ... which has layer instances of its own (kernels_td3.hip)
+      td3_regate_xc(P, S, A, ldxc, agent, idx, nrows, head, true, M, tid, GS_CRITIC2_T_S, 0, row0);
+      for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+        const int row = e / A, col = e - row * A;
+        float a = M.topa[row * lda + col];
+        if (agate) a *= ddrl_gate_factor(agate[col], P.gm.ac_bern, P.gm.ac_scale, P.gm.seed, P.gm.draw, agent, GS_CRITIC2_T_A, row0 + row, col);
+        M.xc[row * ldxc + S + col] = a;
+      }
+    }
+  } else if (step == 14 || step == 15) { // TD3, Bernoulli gates: the critic's input tile again with qnn2's (14) / qnn's (15) masks
+    if (bern) td3_regate_xc(P, S, A, ldxc, agent, idx, nrows, head, false, M, tid, step == 14 ? GS_CRITIC2_S : GS_CRITIC_S,
+                            step == 14 ? GS_CRITIC2_A_REPLAY : GS_CRITIC_A_REPLAY, row0);
   } else if (step == 8) {                // TD3: [s|a] tiles + y = r + gamma min(Q1', Q2') (:317-326)
-    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid);
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, nrows, head, false, M, tid, 0, row0);
     int trow;
     if (gather_owns_row(tid, trow)) {
       const float qn = fminf(M.nrew[trow], M.topq[trow * ldq]);
@@ -373,8 +389,13 @@ wide_step_kernel(const DdpgParams P, int step, int policy) {
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, h = e - row * A;
       float out = M.topa[row * lda + h];
-      const float gt = agate ? agate[h] : 1.f;
-      float diff = W.da[row * ldda + h] * gt;
+      float gin = 1.f, gt = 1.f;          // the masks of the forward passes these gradients belong to
+      if (agate) {
+        const GateMode &gm = P.gm;
+        gin = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_CRITIC_A, row0 + row, h);
+        gt = ddrl_gate_factor(agate[h], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_ACTOR_OUT, row0 + row, h);
+      }
+      float diff = W.da[row * ldda + h] * gin;
       if (P.inverting) {
         if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
         else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
@@ -428,7 +449,9 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
   if (td3) {
     // y = r + gamma min(Q1', Q2')(s', clip(pi'(s') + eps)), then both critics learn it (:304-330)
     step(0); fwd(0, 1); step(6); fwd(1, 1); step(7); fwd(2, 1); step(8);
+    const bool bern = (P.sgate || P.agate) && (P.gm.st_bern || P.gm.ac_bern);
     for (int k = 1; k <= 2; ++k) {
+      if (k == 2 && bern) step(14);
       fwd(k, 0); step(k == 1 ? 3 : 9);
       for (int l = P.q.L_ - 1; l >= 0; --l) { if (l > 0) dx(k, l, 0); dw(k, l); }
       WIDE_CHECK();
@@ -436,7 +459,8 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
     }
     if (!any_actor) return hipSuccess;
     policy = 1;                                             // the delayed actor update through the first critic (:333-363)
-    fwd(0, 0); step(1); fwd(1, 0); step(4);
+    if (bern) step(15);
+    fwd(0, 0); step(13); fwd(1, 0); step(4);
     for (int l = P.q.L_ - 1; l >= 1; --l) dx(1, l, 0);
     dx(1, 0, 1);
     step(5);
@@ -450,7 +474,7 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
   WIDE_CHECK();
   if ((e = finish(1)) != hipSuccess) return e;
   // actor: dQ/da through the NEW critic, inverting gradients, actor backward (:411-459)
-  fwd(0, 0); step(1); fwd(1, 0); step(4);
+  fwd(0, 0); step(13); fwd(1, 0); step(4);
   for (int l = P.q.L_ - 1; l >= 1; --l) dx(1, l, 0);
   dx(1, 0, 1);
   step(5);

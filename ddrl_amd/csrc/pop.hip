@@ -685,8 +685,7 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   h->P.mask = dmask;
   h->P.sgate = h->gates_on ? h->d_sgate : nullptr;
   h->P.agate = h->gates_on ? h->d_agate : nullptr;
-  if (h->gates_on && bernoulli_gates(h) && (h->wide || h->bn))
-    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the layer-by-layer path (widths > %d)", DDRL_MAXW);
+  if (h->gates_on && bernoulli_gates(h) && h->bn) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served together with BatchNorm towers");
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
   h->P.nupd = per_launch;
@@ -793,8 +792,6 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
   P.mask = dmask;
   P.sgate = h->gates_on ? h->d_sgate : nullptr;
   P.agate = h->gates_on ? h->d_agate : nullptr;
-  if (h->gates_on && bernoulli_gates(h) && (h->wide || P.maxchunks > 1 || h->force_chunked))
-    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are served by the one-tile TD3 update only (minibatches <= 64 rows, layers <= 128 wide)");
   P.gm = next_draw(h, 1);
   P.sa = h->net[0].st; P.sq = h->net[1].st; P.sq2 = h->net[2].st;
   P.actor_step = actor_step ? h->d_astep : nullptr;
@@ -924,8 +921,7 @@ extern "C" int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *act
 // *_scale divides a passed value by w.  seed starts the counter-based draw stream again.
 extern "C" int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
-  if ((h->wide || (h->P.maxchunks > 1 && h->nnets == 3)) && (st_bernoulli || ac_bernoulli))
-    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are served by the DDPG updates of layers <= 128 wide (any minibatch), the one-tile TD3 update and NFAC only");
+  if (h->bn && (st_bernoulli || ac_bernoulli)) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served together with BatchNorm towers");
   h->gm.st_bern = st_bernoulli ? 1 : 0; h->gm.st_scale = st_scale ? 1 : 0;
   h->gm.ac_bern = ac_bernoulli ? 1 : 0; h->gm.ac_scale = ac_scale ? 1 : 0;
   h->gm.seed = seed; h->gm.draw = 0;

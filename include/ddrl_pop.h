@@ -201,8 +201,8 @@ int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate);
  * (CaffeUtest.cpp:1126-1131).  *_bernoulli = 0 (default; probabilist = 1): the stored gate multiplies.  Every forward
  * pass of every layer instance draws its own mask, a backward pass re-creates its forward pass's mask (counter-based
  * generator keyed on seed / pass / agent / layer instance / row / dimension: the fork's generator is unknown, only the
- * pass rates are pinned).  Served by the DDPG updates of layers <= 128 wide (any minibatch size), the one-tile TD3 update
- * (minibatches <= 64 rows), NFAC, infer and forward_batch; DDRL_EINVAL elsewhere (the layer-by-layer path, chunked TD3). */
+ * pass rates are pinned).  Served by every DDPG / TD3 update path (one-tile, chunked, layer-by-layer), NFAC, infer and
+ * forward_batch; DDRL_EINVAL together with BatchNorm towers. */
 int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed);
 /* DODevMLP's view of a net's parameters: after DODevMLP::exploit (DODevMLP.hpp:216-401) the gate weights are blobs of the
  * net, so number_of_parameters / copyWeightsTo / copyWeightsFrom (MLP.hpp:610-676) count and carry them:

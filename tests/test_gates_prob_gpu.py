@@ -229,24 +229,20 @@ def test_nfac_update_given_masks(ora):
 
 def test_refused_where_not_served(ora):
     import ddrl_amd
-    pop, _ = make_pair(ora, G=2, B=64, hidden_a=(200, 100), hidden_q=(100, 100), n_replay=300)       # a layer wider than 128: layer-by-layer launches
-    with pytest.raises(ddrl_amd.DdrlError, match="128 wide"):
-        pop.set_gate_mode(1, 0, 1, 0, seed=1)
-    pop.set_gate_mode(0, 0, 0, 0)
-    pop.close()
-    import test_td3_gpu as t3
-    pop, _ = t3.make_td3(ora, G=2, B=128, hidden_a=(64, 32), hidden_q=(48, 40), n_replay=300)        # TD3 over two minibatch tiles
-    with pytest.raises(ddrl_amd.DdrlError, match="one-tile TD3"):
+    pop, _ = make_pair(ora, G=2, hidden_a=(20, 10), hidden_q=(20, 10), n_replay=300, batch_norm_actor=14, batch_norm_critic=11)
+    with pytest.raises(ddrl_amd.DdrlError, match="BatchNorm"):
         pop.set_gate_mode(1, 0, 1, 0, seed=1)
     pop.close()
 
 
-@pytest.mark.parametrize("B,scale", [(128, 1), (160, 0)])
-def test_ddpg_chunked_update_given_masks(ora, B, scale):
-    """Minibatches of more than 64 rows (chunk + apply kernels, kernels_ddpg_big.hip) with Bernoulli gates: the masks are drawn per
-    MINIBATCH row, so the oracle fed the generator's masks for rows 0 .. B-1 must agree whatever the chunking."""
+@pytest.mark.parametrize("B,hidden_a,hidden_q,scale", [(128, (64, 32), (48, 40), 1), (160, (64, 32), (48, 40), 0),
+                                                       (64, (200, 100), (150, 130), 1), (96, (40, 160), (140, 20), 0)])
+def test_ddpg_chunked_and_wide_updates_given_masks(ora, B, hidden_a, hidden_q, scale):
+    """Minibatches of more than 64 rows (chunk + apply kernels, kernels_ddpg_big.hip) and layers wider than 128 (layer-by-layer
+    launches, kernels_ddpg_wide.hip) with Bernoulli gates: the masks are drawn per MINIBATCH row, so the oracle fed the
+    generator's masks for rows 0 .. B-1 must agree whatever the chunking."""
     G, S, A = 2, 18, 6
-    pop, agents = make_pair(ora, G=G, B=B, hidden_a=(64, 32), hidden_q=(48, 40), wscale=0.1, seed=11)
+    pop, agents = make_pair(ora, G=G, B=B, hidden_a=hidden_a, hidden_q=hidden_q, wscale=0.1 if max(hidden_a + hidden_q) <= 128 else 0.05, seed=11)
     rng = np.random.RandomState(6)
     sg = np.round(rng.uniform(0.3, 1, (G, S)), 2); sg[:, ::3] = 1.0
     ag = np.round(rng.uniform(0.3, 1, (G, A)), 2); ag[:, 0] = 1.0
@@ -369,4 +365,39 @@ def test_td3_update_given_masks(ora, scale):
         p.close()
     for x, y in zip(*res):
         assert np.array_equal(x, y)
+    pop.close()
+
+
+@pytest.mark.parametrize("B,hidden_a,hidden_q", [(128, (64, 32), (48, 40)), (160, (64, 32), (48, 40)), (96, (200, 100), (150, 130))])
+def test_td3_chunked_and_wide_updates_given_masks(ora, B, hidden_a, hidden_q):
+    """TD3 over several minibatch tiles (ddpg_chunk_kernel<.., TD3>) and over layers wider than 128 (layer-by-layer launches) with
+    Bernoulli gates, against the oracle fed the device's masks"""
+    import test_td3_gpu as t3
+    G, S, A, scale = 2, 18, 6, 1
+    C2_T_S, C2_T_A, C2_S, C2_A_REPLAY = 17, 18, 19, 20
+    pop, agents = t3.make_td3(ora, G=G, B=B, hidden_a=hidden_a, hidden_q=hidden_q, seed=6, wscale=0.1 if max(hidden_a + hidden_q) <= 128 else 0.05)
+    rng = np.random.RandomState(8)
+    sg = np.round(rng.uniform(0.3, 1, (G, S)), 2); sg[:, ::3] = 1.0
+    ag = np.round(rng.uniform(0.3, 1, (G, A)), 2); ag[:, 0] = 1.0
+    sg = sg.astype(np.float32).astype(np.float64); ag = ag.astype(np.float32).astype(np.float64)
+    pop.set_gates(sg, ag)
+    seed = 131
+    for upd, astep in enumerate([np.array([1, 1], np.uint8), np.array([0, 1], np.uint8)]):
+        pop.set_gate_mode(1, scale, 1, scale, seed=seed + upd)
+        idx = np.random.RandomState(70 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        noise = np.random.RandomState(80 + upd).normal(0, 0.1, (G, B, A)).astype(np.float32)
+        for g, a in enumerate(agents):
+            F = lambda wv, site: gate_factors(wv, 1, scale, seed + upd, 0, g, site, B)
+            cat = lambda s_site, a_site: np.concatenate([F(sg[g], s_site), F(ag[g], a_site)], 1)
+            a.ann_target.push_row_gates(F(sg[g], ACTOR_T_S), F(ag[g], ACTOR_T_OUT), B)
+            a.qnn_target.push_row_gates(cat(CRITIC_T_S, CRITIC_T_A), None, B)
+            a.qnn_target2.push_row_gates(cat(C2_T_S, C2_T_A), None, B)
+            a.qnn.push_row_gates(cat(CRITIC_S, CRITIC_A_REPLAY), None, B)
+            a.qnn2.push_row_gates(cat(C2_S, C2_A_REPLAY), None, B)
+            if astep[g]:
+                a.ann.push_row_gates(F(sg[g], ACTOR_S), F(ag[g], ACTOR_OUT), B)
+                a.qnn.push_row_gates(cat(CRITIC_S, CRITIC_A), None, B)
+        t3.step_and_check(pop, agents, idx, noise, astep)
+        for a in agents:
+            assert all(n.row_gates_pending() == 0 for n in a.nets)
     pop.close()
