@@ -334,6 +334,8 @@ struct ddrl_cmaes {
   double gen = 0, countevals = 0, genOfEigensysUpdate = 0;
   int state = 0, eigen_uptodate = 1;
   int device_eigen = 0;                  // throughput mode: one-sided Jacobi on the GPU instead of the host JAMA routines
+  int eigen_block = 1;                   // ... with blocks of rows as the tournament's players (cmaes_jacobi_block_round) instead of single rows
+  int sweep_graph_block = 0;             // which of the two the captured sweep holds
   int eigen_sweeps = 0;                  // sweeps the last device eigendecomposition took
   hipGraphExec_t sweep_graph = nullptr;  // one Jacobi sweep (N - 1 rounds) as a captured graph
   bool sweep_graph_failed = false;
@@ -649,6 +651,245 @@ cmaes_jacobi_round(double *__restrict__ G, double *__restrict__ W, int N, int n2
   if (tid == 0) atomicAdd(rotated, 1);
 }
 
+// BLOCKED rounds (round 3; option "eigen_block", default on).  The rounds above are launch-bound: a workgroup rotates two rows
+// of 631 doubles and is gone in 6.9 us, 630 times a sweep.  Here the players of the tournament are blocks of JB = 8 rows: a
+// workgroup takes the two blocks it is dealt (16 rows), forms their 16 x 16 Gram matrix S = A A^T (the only pass over the rows:
+// staged through LDS in 64-column chunks), runs ONE cyclic sweep of the same rotations on S itself -- 15 steps of 8 disjoint
+// pairs, S <- R S R^T, accumulating T <- R T, every rotation chosen exactly as the row kernel chooses it from (|g_p|^2, |g_q|^2,
+// g_p . g_q) -- and then applies T to the 16 rows of G and W in one more pass.  A sweep is ceil(N / 8) - 1 rounds (78 instead of
+// 630 at N = 631); every pair of rows still meets once per sweep (pairs inside a block more often), and convergence is judged
+// by the same per-pair test, counted over a whole sweep.
+#define JB 8
+#define JT 1024      // threads of a blocked round: the two passes over the rows use all of them, the 16 x 16 sweep the first 256
+__global__ void __launch_bounds__(JT)
+cmaes_jacobi_block_round(double *__restrict__ G, double *__restrict__ W, int N, int nb2, int step, int *__restrict__ rotated) {
+  __shared__ double tile[2 * JB][257];              // a 256-column chunk of the 16 rows
+  __shared__ double part[3][256];                   // partial Gram sums of the column quarters 1..3
+  __shared__ double S[2 * JB][2 * JB + 1], T[2 * JB][2 * JB + 1];
+  __shared__ double cc[2 * JB], ss[2 * JB];
+  __shared__ int partner[2 * JB], rows[2 * JB], nrot;
+  const int tid = threadIdx.x, b = blockIdx.x, m = nb2 - 1;
+  int P, Q;
+  if (b == 0) { P = m; Q = step; }
+  else { P = (step + b) % m; Q = (step - b + m) % m; }
+  if (P * JB >= N && Q * JB >= N) return;          // (a block beyond N is a bye: its partner still rotates inside itself)
+  if (P > Q) { const int t = P; P = Q; Q = t; }
+  if (tid < 2 * JB) { const int ri = tid < JB ? P * JB + tid : Q * JB + tid - JB; rows[tid] = ri < N ? ri : -1; }
+  if (tid == 0) nrot = 0;
+  __syncthreads();
+  const int e = tid & 255, x = e >> 4, y = e & 15, kq = tid >> 8;     // this thread's entry of the 16 x 16 matrices, its quarter of a chunk
+  // ---- S = A A^T over the 16 rows ----
+  double acc = 0.;
+#pragma unroll 1
+  for (int c0 = 0; c0 < N; c0 += 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + JT * q, r = f >> 8, k = f & 255, ri = rows[r];
+      tile[r][k] = ri >= 0 && c0 + k < N ? G[(size_t)ri * N + c0 + k] : 0.;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int k = 64 * kq; k < 64 * kq + 64; ++k) acc += tile[x][k] * tile[y][k];
+    __syncthreads();
+  }
+  if (kq > 0) part[kq - 1][e] = acc;
+  __syncthreads();
+  if (kq == 0) {
+    S[x][y] = (acc + part[0][e]) + (part[1][e] + part[2][e]);
+    T[x][y] = x == y ? 1. : 0.;
+  }
+  __syncthreads();
+  // ---- one cyclic sweep on S: 15 steps of 8 disjoint pairs (the same tournament over 16 players) ----
+#pragma unroll 1
+  for (int st = 0; st < 2 * JB - 1; ++st) {
+    if (tid < JB) {
+      const int mm = 2 * JB - 1;
+      int a, c;
+      if (tid == 0) { a = mm; c = st; }
+      else { a = (st + tid) % mm; c = (st - tid + mm) % mm; }
+      if (a > c) { const int t = a; a = c; c = t; }
+      const double al = S[a][a], be = S[c][c], ga = S[a][c];
+      double co = 1., sn = 0.;
+      if (fabs(ga) > 1e-9 * sqrt(al * be)) {        // the row kernel's test and rotation (rows a, c of the pair)
+        const double zeta = (be - al) / (2. * ga);
+        const double t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+        co = 1. / sqrt(1. + t * t); sn = co * t;
+        atomicAdd(&nrot, 1);
+      }
+      // new_a = co a - sn c, new_c = sn a + co c
+      partner[a] = c; partner[c] = a;
+      cc[a] = co; ss[a] = -sn; cc[c] = co; ss[c] = sn;
+    }
+    __syncthreads();
+    double s_new = 0., t_new = 0.;
+    if (kq == 0) {
+      const int px = partner[x], py = partner[y];
+      s_new = cc[x] * (cc[y] * S[x][y] + ss[y] * S[x][py]) + ss[x] * (cc[y] * S[px][y] + ss[y] * S[px][py]);
+      t_new = cc[x] * T[x][y] + ss[x] * T[px][y];
+    }
+    __syncthreads();
+    if (kq == 0) { S[x][y] = s_new; T[x][y] = t_new; }
+    __syncthreads();
+  }
+  if (nrot == 0) return;                            // uniform: these 16 rows are orthogonal enough already
+  if (tid == 0) atomicAdd(rotated, nrot);
+  // ---- rows <- T rows, for G and W ----
+#pragma unroll 1
+  for (int which = 0; which < 2; ++which) {
+    double *M = which ? W : G;
+#pragma unroll 1
+    for (int k = tid; k < N; k += JT) {
+      double v[2 * JB];
+#pragma unroll
+      for (int r = 0; r < 2 * JB; ++r) { const int ri = rows[r]; v[r] = ri >= 0 ? M[(size_t)ri * N + k] : 0.; }
+#pragma unroll 1                                     // (rolled: unrolled, the 256 entries of T are hoisted out of the column loop into 512 registers)
+      for (int r = 0; r < 2 * JB; ++r) {
+        const int ri = rows[r];
+        if (ri >= 0) {
+          double o = 0.;
+#pragma unroll
+          for (int u = 0; u < 2 * JB; ++u) o += T[r][u] * v[u];
+          M[(size_t)ri * N + k] = o;
+        }
+      }
+    }
+  }
+}
+
+// The same round for N <= 1024 (every policy of BASELINE.md): ONE trip to memory.  Thread k owns columns k and k + 512 of the 16 rows: it
+// fetches its 16 + 16 values of G and W at once (the rows were written by other workgroups in the previous round, so every
+// dependent access costs a device-level round trip -- the round above makes five of them in a row), parks the G values in LDS
+// for the Gram sums, and applies T to both from LDS / registers.  The 16 x 16 sweep runs in the first WAVE alone, ordered by
+// that wave's own LDS ordering instead of 45 workgroup barriers; the rotation's tangent is computed in fp32 (it only steers
+// the iteration), its cosine from the tangent in fp64 (a Newton-refined reciprocal square root: c^2 + s^2 = 1 to fp64 rounding).
+__device__ __forceinline__ void jacobi_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#define JF 512       // threads of the one-trip round: two columns each
+__global__ void __launch_bounds__(JF)
+cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, int ldt, int nb2, int step, int *__restrict__ rotated) {
+  extern __shared__ __align__(16) double jsm[];
+  double *tile = jsm;                               // [16][ldt]: the G rows
+  double *S = tile + 2 * JB * ldt, *T = S + 2 * JB * (2 * JB + 1);     // [16][17], [16][16]
+  double *cc = T + 2 * JB * 2 * JB, *ss = cc + 2 * JB;
+  __shared__ int nrot;
+  const int tid = threadIdx.x, b = blockIdx.x, m = nb2 - 1, LS = 2 * JB + 1, LT = 2 * JB;
+  int P, Q;
+  if (b == 0) { P = m; Q = step; }
+  else { P = (step + b) % m; Q = (step - b + m) % m; }
+  if (P * JB >= N && Q * JB >= N) return;
+  if (P > Q) { const int t = P; P = Q; Q = t; }
+  auto row_of = [&](int r) { const int ri = r < JB ? P * JB + r : Q * JB + r - JB; return ri < N ? ri : -1; };
+  double vg[2][2 * JB], vw[2][2 * JB];              // columns tid and tid + JF of the 16 rows
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = tid + JF * h;
+#pragma unroll
+    for (int r = 0; r < 2 * JB; ++r) {
+      const int ri = row_of(r);
+      const bool in = ri >= 0 && k < N;
+      vg[h][r] = in ? G[(size_t)ri * N + k] : 0.;
+      vw[h][r] = in ? W[(size_t)ri * N + k] : 0.;
+      if (k < ldt) tile[r * ldt + k] = vg[h][r];
+    }
+  }
+  if (tid == 0) nrot = 0;
+  __syncthreads();
+  {
+    // S = A A^T: a 2 x 2 tile of S per thread (rows 2 tx, 2 tx + 1 against rows 2 ty, 2 ty + 1: four LDS reads feed four
+    // products), 64 tiles x 8 column slices; the slices are the low three bits of the lane, summed by butterfly
+    const int lane = tid & 63, sl = lane & 7, t64 = (tid >> 6) * 8 + (lane >> 3), tx = t64 >> 3, ty = t64 & 7;
+    const double *x0 = tile + (2 * tx) * ldt, *x1 = x0 + ldt, *y0 = tile + (2 * ty) * ldt, *y1 = y0 + ldt;
+    double a00 = 0., a01 = 0., a10 = 0., a11 = 0.;
+    for (int kk = sl; kk < N; kk += 8) {
+      const double p0 = x0[kk], p1 = x1[kk], q0 = y0[kk], q1 = y1[kk];
+      a00 += p0 * q0; a01 += p0 * q1; a10 += p1 * q0; a11 += p1 * q1;
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      a00 += __shfl_xor(a00, o); a01 += __shfl_xor(a01, o); a10 += __shfl_xor(a10, o); a11 += __shfl_xor(a11, o);
+    }
+    if (sl == 0) {
+      S[(2 * tx) * LS + 2 * ty] = a00; S[(2 * tx) * LS + 2 * ty + 1] = a01;
+      S[(2 * tx + 1) * LS + 2 * ty] = a10; S[(2 * tx + 1) * LS + 2 * ty + 1] = a11;
+    }
+    if (tid < 256) T[tid] = (tid >> 4) == (tid & 15) ? 1. : 0.;
+  }
+  __syncthreads();
+  if (tid < 64) {                                   // ---- the 16 x 16 sweep, first wave only ----
+    const int yy = tid & 15, xg = tid >> 4;         // this lane's entries: rows 4 xg .. 4 xg + 3 of column yy
+    const int mm = 2 * JB - 1;
+    // Round 0 of a sweep rotates all 120 pairs of the 16 rows (15 steps: player 15 meets st, the others p <-> (2 st - p) mod 15);
+    // the other rounds only the 64 pairs ACROSS the two blocks (8 steps: row p of the first block meets row (p + st) mod 8 of
+    // the second) -- the pairs inside a block have had their turn in round 0, where every block plays (a block with a bye
+    // plays alone)
+    const bool full = step == 0;
+    auto partner_of = [&](int p, int st) {
+      if (!full) return p < JB ? JB + ((p + st) & (JB - 1)) : ((p - st) & (JB - 1));
+      if (p == mm) return st;
+      if (p == st) return mm;
+      int q = (2 * st - p) % mm;
+      return q < 0 ? q + mm : q;
+    };
+    const int nst = full ? 2 * JB - 1 : JB;
+    for (int st = 0; st < nst; ++st) {
+      if (tid < 2 * JB) {                           // lane p: the rotation of its own pair, its own row's coefficients
+        const int p = tid, q = partner_of(p, st), a = p < q ? p : q, c = p < q ? q : p;
+        const double al = S[a * LS + a], be = S[c * LS + c], ga = S[a * LS + c];
+        double co = 1., sn = 0.;
+        if (ga * ga > 1e-18 * (al * be)) {          // |g_a . g_c| > 1e-9 |g_a| |g_c|
+          const float zeta = (float)(be - al) / (2.f * (float)ga);
+          const float tf = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+          const double t = (double)tf, qq = 1. + t * t;
+          double r = (double)rsqrtf((float)qq);     // 1 / sqrt(1 + t^2): fp32 seed, two Newton steps
+          r = r * (1.5 - 0.5 * qq * r * r);
+          r = r * (1.5 - 0.5 * qq * r * r);
+          co = r; sn = r * t;
+          if (p == a) atomicAdd(&nrot, 1);
+        }
+        cc[p] = co; ss[p] = p == a ? -sn : sn;      // new_a = co a - sn c, new_c = sn a + co c
+      }
+      jacobi_wave_fence();
+      double sn4[4], tn4[4];
+      const int py = partner_of(yy, st);
+      const double cy = cc[yy], sy = ss[yy];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int xx = 4 * xg + i, px = partner_of(xx, st);
+        const double cx = cc[xx], sx = ss[xx];
+        sn4[i] = cx * (cy * S[xx * LS + yy] + sy * S[xx * LS + py]) + sx * (cy * S[px * LS + yy] + sy * S[px * LS + py]);
+        tn4[i] = cx * T[xx * LT + yy] + sx * T[px * LT + yy];
+      }
+      jacobi_wave_fence();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { S[(4 * xg + i) * LS + yy] = sn4[i]; T[(4 * xg + i) * LT + yy] = tn4[i]; }
+      jacobi_wave_fence();
+    }
+  }
+  __syncthreads();
+  if (nrot == 0) return;                            // uniform
+  if (tid == 0) atomicAdd(rotated, nrot);
+  if (tid >= N) return;
+#pragma unroll 1
+  for (int r = 0; r < 2 * JB; ++r) {                // (rolled: see cmaes_jacobi_block_round)
+    const int ri = row_of(r);
+    if (ri >= 0) {
+      const double *tr = T + r * LT;
+      double og0 = 0., ow0 = 0., og1 = 0., ow1 = 0.;
+#pragma unroll
+      for (int u = 0; u < 2 * JB; ++u) { const double t = tr[u]; og0 += t * vg[0][u]; ow0 += t * vw[0][u]; og1 += t * vg[1][u]; ow1 += t * vw[1][u]; }
+      G[(size_t)ri * N + tid] = og0;
+      W[(size_t)ri * N + tid] = ow0;
+      if (tid + JF < N) { G[(size_t)ri * N + tid + JF] = og1; W[(size_t)ri * N + tid + JF] = ow1; }
+    }
+  }
+}
+extern "C" size_t cmaes_jacobi_fast_lds(int ldt) {
+  return ((size_t)2 * JB * ldt + (2 * JB) * (2 * JB + 1) + (2 * JB) * (2 * JB) + 2 * (2 * JB)) * sizeof(double);
+}
+
 // lambda_i = g_i . w_i, D_i = sqrt(max(lambda_i, 0)), B[:, i] = w_i (fp32, the sampling GEMM's operand)
 __global__ void __launch_bounds__(256)
 cmaes_jacobi_finish(const double *__restrict__ G, const double *__restrict__ W, int N, int ldn, double *__restrict__ ev,
@@ -666,7 +907,24 @@ cmaes_jacobi_finish(const double *__restrict__ G, const double *__restrict__ W, 
 }
 
 static int device_eigen(ddrl_cmaes *h) {
-  const int N = h->N, n2 = (N + 1) / 2 * 2;
+  const int N = h->N;
+  // players of a sweep's tournament: blocks of JB rows (eigen_block) or single rows
+  const int nplayers = h->eigen_block ? (N + JB - 1) / JB : N, n2 = h->eigen_block ? (nplayers < 2 ? 2 : (nplayers + 1) / 2 * 2) : (N + 1) / 2 * 2;
+  const int ldt = N | 1;                            // LDS row stride of the one-trip kernel (odd: the Gram sums' two row reads spread over the banks)
+  const bool fast = h->eigen_block && N <= 2 * JF && cmaes_jacobi_fast_lds(ldt) <= 150 * 1024;
+  if (fast) {
+    static LdsConfig conf;
+    HIPCHK(ddrl_set_lds(cmaes_jacobi_block_fast, cmaes_jacobi_fast_lds(ldt), conf));
+  }
+  auto round = [&](int step) {
+    if (fast) hipLaunchKernelGGL(cmaes_jacobi_block_fast, dim3(n2 / 2), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, step, h->d_info);
+    else if (h->eigen_block) hipLaunchKernelGGL(cmaes_jacobi_block_round, dim3(n2 / 2), dim3(JT), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
+    else hipLaunchKernelGGL(cmaes_jacobi_round, dim3(n2 / 2), dim3(256), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
+  };
+  if (h->sweep_graph && h->sweep_graph_block != h->eigen_block) {     // the option changed: the captured sweep is the other kernel's
+    (void)hipGraphExecDestroy(h->sweep_graph);
+    h->sweep_graph = nullptr;
+  }
   if (h->eig_warm) {       // Cs = C in fp64 (d_Cs), G = W_prev Cs; W keeps the previous eigenvectors
     hipLaunchKernelGGL(cmaes_jacobi_init, dim3((N + 63) / 64, N), dim3(64), 0, h->stream, h->d_C, h->ldn, N, h->d_Cs, (double *)nullptr);
     hipLaunchKernelGGL(cmaes_jacobi_warm, dim3((N + 255) / 256, N), dim3(256), 0, h->stream, h->d_W, h->d_Cs, N, h->d_A);
@@ -681,11 +939,11 @@ static int device_eigen(ddrl_cmaes *h) {
       hipGraph_t g = nullptr;
       bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (ok) {
-        for (int step = 0; step < n2 - 1; ++step)
-          hipLaunchKernelGGL(cmaes_jacobi_round, dim3(n2 / 2), dim3(256), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
+        for (int step = 0; step < n2 - 1; ++step) round(step);
         ok = hipStreamEndCapture(h->stream, &g) == hipSuccess && g;
       }
       if (ok) ok = hipGraphInstantiate(&h->sweep_graph, g, nullptr, nullptr, 0) == hipSuccess;
+      h->sweep_graph_block = h->eigen_block;
       if (g) (void)hipGraphDestroy(g);
       if (!ok) { h->sweep_graph = nullptr; h->sweep_graph_failed = true; (void)hipGetLastError(); }
     }
@@ -694,8 +952,7 @@ static int device_eigen(ddrl_cmaes *h) {
       if (h->sweep_graph) {
         HIPCHK(hipGraphLaunch(h->sweep_graph, h->stream));
       } else {
-        for (int step = 0; step < n2 - 1; ++step)
-          hipLaunchKernelGGL(cmaes_jacobi_round, dim3(n2 / 2), dim3(256), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
+        for (int step = 0; step < n2 - 1; ++step) round(step);
       }
       HIPCHK(hipGetLastError());
       int rotated = 0;
@@ -1181,7 +1438,8 @@ extern "C" int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int m
 
 // options (throughput modes; same algorithm, not seed-for-seed comparable with c-cmaes):
 //   "device_rng" (0/1): draw z on the device (Philox) instead of evaluating c-cmaes' sequential
-//   generator on the host;  "device_eigen" (0/1): eigendecomposition by one-sided Jacobi on the GPU (device_eigen above).
+//   generator on the host;  "device_eigen" (0/1): eigendecomposition by one-sided Jacobi on the GPU (device_eigen above);
+//   "eigen_block" (1/0): its rounds over blocks of rows (default) or over single rows.
 extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value) {
   if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (std::string(key) == "device_rng") { h->device_rng = value != 0; return DDRL_OK; }
@@ -1197,6 +1455,7 @@ extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value
     h->eig_warm = 0;
     return DDRL_OK;
   }
+  if (std::string(key) == "eigen_block") { h->eigen_block = value != 0; return DDRL_OK; }      // 1 (default): blocked rounds; 0: one row pair per workgroup
   return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);
 }
 

@@ -455,7 +455,8 @@ int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int msg_len);
 /* options: "device_rng" (0/1) -- throughput mode: z ~ N(0, I) is drawn on the GPU from a counter-based
  * generator (Philox4x32-10) instead of c-cmaes' sequential LCG stream evaluated on the host
  * (cmaes.c:2421-2482); "device_eigen" (0/1): the eigendecomposition (cmaes.c:1885-1947, O(N^3) on
- * the host otherwise) by this library's one-sided Jacobi kernels in fp64 on the GPU.  Same algorithm, different stream /
+ * the host otherwise) by this library's one-sided Jacobi kernels in fp64 on the GPU; "eigen_block" (1/0, default 1): their rounds
+ * over blocks of 8 rows (78 launches per sweep at N = 631) instead of single rows (630).  Same algorithm, different stream /
  * eigenbasis: no counterpart in the reference. */
 int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value);
 
