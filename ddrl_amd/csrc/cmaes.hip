@@ -336,6 +336,8 @@ struct ddrl_cmaes {
   int device_eigen = 0;                  // throughput mode: one-sided Jacobi on the GPU instead of the host JAMA routines
   int eigen_block = 1;                   // ... with blocks of rows as the tournament's players (cmaes_jacobi_block_round) instead of single rows
   int sweep_graph_block = 0;             // which of the two the captured sweep holds
+  int eigen_persist = 1;                 // ... and all sweeps in one launch with barriers in memory (cmaes_jacobi_sweeps_fast) where the one-trip round serves
+  int eigen_persist_timeouts = 0;        // launches that gave up at a barrier (and were finished round by round)
   int eigen_sweeps = 0;                  // sweeps the last device eigendecomposition took
   hipGraphExec_t sweep_graph = nullptr;  // one Jacobi sweep (N - 1 rounds) as a captured graph
   bool sweep_graph_failed = false;
@@ -768,109 +770,162 @@ __device__ __forceinline__ void jacobi_wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 #define JF 512       // threads of the one-trip round: two columns each
-__global__ void __launch_bounds__(JF)
-cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, int ldt, int nb2, int step, int *__restrict__ rotated) {
-  extern __shared__ __align__(16) double jsm[];
+typedef double jf_f64x4 __attribute__((ext_vector_type(4)));
+
+// One cyclic sweep on the 16 x 16 Gram matrix S (LDS), rotations accumulated in T (LDS); one wave.  FULL: all 120 pairs of the 16
+// rows (15 steps: player 15 meets st, the others p <-> (2 st - p) mod 15); otherwise only the 64 pairs ACROSS the two blocks
+// (8 steps: row p of the first block meets row (p + st) mod 8 of the second) -- the pairs inside a block have had their turn
+// in round 0 of the sweep, where every block plays (a block with a bye plays alone).
+// A step is one wave's chain of dependent instructions, so it is kept short: lane (xg, yy) owns rows 4 xg .. 4 xg + 3 of column
+// yy and computes the rotation of ROW yy's pair itself (four lanes each; the column's coefficients are then at hand), fetches
+// everything it will combine before that arithmetic starts, and gets its rows' coefficients from the lanes that hold them
+// (no trip through LDS).  The tangent only steers the iteration: hardware reciprocal / square root in fp32 (|zeta| beyond
+// 1e15: t = 1 / (2 zeta), where 1 + zeta^2 leaves fp32); the cosine is 1 / sqrt(1 + t^2) in fp64 (fp32 seed, two Newton steps).
+template <bool FULL>
+__device__ __forceinline__ void jacobi_tile_sweep(double *S, double *T, int lane, int *nrot, int *worst) {
+  constexpr int LS = 2 * JB + 1, LT = 2 * JB, mm = 2 * JB - 1, nst = FULL ? 2 * JB - 1 : JB;
+  const int yy = lane & 15, xg = lane >> 4;
+  auto partner_of = [&](int p, int st) {
+    if (!FULL) return p < JB ? JB + ((p + st) & (JB - 1)) : ((p - st) & (JB - 1));
+    int q = (2 * st - p + 2 * mm) % mm;             // (p, st < 15: the sum is positive)
+    q = p == st ? mm : q;
+    return p == mm ? st : q;
+  };
+  int mine = 0;                                     // rotations this lane counted (lane a < 16 of each pair), their worst ratio
+  float bad = 0.f;
+#pragma unroll 1
+  for (int st = 0; st < nst; ++st) {
+    const int py = partner_of(yy, st), a = yy < py ? yy : py, c = yy < py ? py : yy;
+    const double al = S[a * LS + a], be = S[c * LS + c], ga = S[a * LS + c];
+    double sxy[4], sxp[4], spy[4], spp[4], tx[4], tp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xx = 4 * xg + i, px = partner_of(xx, st);
+      sxy[i] = S[xx * LS + yy]; sxp[i] = S[xx * LS + py]; spy[i] = S[px * LS + yy]; spp[i] = S[px * LS + py];
+      tx[i] = T[xx * LT + yy]; tp[i] = T[px * LT + yy];
+    }
+    const bool rot = ga * ga > 1e-18 * (al * be);   // |g_a . g_c| > 1e-9 |g_a| |g_c|
+    const float zeta = (float)((be - al) * __builtin_amdgcn_rcp(2. * ga)), az = fabsf(zeta);
+    float tf = az > 1e15f ? 0.5f * __builtin_amdgcn_rcpf(az) : __builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(1.f + az * az));
+    tf = zeta >= 0.f ? tf : -tf;
+    const double t = (double)tf, qq = 1. + t * t;
+    double r = (double)__builtin_amdgcn_rsqf((float)qq);
+    r = r * (1.5 - 0.5 * qq * r * r);
+    r = r * (1.5 - 0.5 * qq * r * r);
+    const double cy = rot ? r : 1., sy = rot ? (yy == a ? -(r * t) : r * t) : 0.;      // new_a = co a - sn c, new_c = sn a + co c
+    if (rot && yy == a) { ++mine; bad = fmaxf(bad, (float)(ga * ga) * __builtin_amdgcn_rcpf((float)(al * be))); }
+    double sn4[4], tn4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double cx = __shfl(cy, 4 * xg + i), sx = __shfl(sy, 4 * xg + i);       // row (4 xg + i)'s pair: lane 4 xg + i computed it
+      sn4[i] = cx * (cy * sxy[i] + sy * sxp[i]) + sx * (cy * spy[i] + sy * spp[i]);
+      tn4[i] = cx * tx[i] + sx * tp[i];
+    }
+    jacobi_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { S[(4 * xg + i) * LS + yy] = sn4[i]; T[(4 * xg + i) * LT + yy] = tn4[i]; }
+    jacobi_wave_fence();
+  }
+  if (lane < 2 * JB && mine) { atomicAdd(nrot, mine); atomicMax(worst, __float_as_int(bad)); }
+}
+
+// COH: the rows are read and written with agent-scope accesses (they by-pass the caches that are not shared by all CUs), for the
+// one-launch decomposition, whose workgroups hand rows to each other inside a kernel
+template <bool COH>
+__device__ __forceinline__ double jacobi_ld(const double *p) { return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
+template <bool COH>
+__device__ __forceinline__ void jacobi_st(double *p, double v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ void jacobi_fast_round(double *G, double *W, int N, int ldt, int nb2, int step, int *rotated, double *jsm) {
   double *tile = jsm;                               // [16][ldt]: the G rows
   double *S = tile + 2 * JB * ldt, *T = S + 2 * JB * (2 * JB + 1);     // [16][17], [16][16]
-  double *cc = T + 2 * JB * 2 * JB, *ss = cc + 2 * JB;
-  __shared__ int nrot;
+  double *part = T + 2 * JB * 2 * JB;               // [8 waves][256]: the waves' partial Gram matrices
+  __shared__ int nrot, worst;
   const int tid = threadIdx.x, b = blockIdx.x, m = nb2 - 1, LS = 2 * JB + 1, LT = 2 * JB;
+  (void)LT;
   int P, Q;
   if (b == 0) { P = m; Q = step; }
   else { P = (step + b) % m; Q = (step - b + m) % m; }
   if (P * JB >= N && Q * JB >= N) return;
   if (P > Q) { const int t = P; P = Q; Q = t; }
+#ifdef DDRL_CMAES_STAMPS
+  const long long t0 = wall_clock64();
+  long long t1 = 0, t2 = 0, t3 = 0;
+#endif
   auto row_of = [&](int r) { const int ri = r < JB ? P * JB + r : Q * JB + r - JB; return ri < N ? ri : -1; };
   double vg[2][2 * JB], vw[2][2 * JB];              // columns tid and tid + JF of the 16 rows
+  // every fetch is issued before the first is waited for: the addresses are clamped into the matrix instead of branching round
+  // the load (a conditional load waits for its own data before the next is issued: 32 round trips in a row)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = tid + JF * h, kc = k < N ? k : N - 1;
+#pragma unroll
+    for (int r = 0; r < 2 * JB; ++r) {
+      const int ri = row_of(r);
+      const size_t at = (size_t)(ri >= 0 ? ri : 0) * N + kc;
+      vg[h][r] = jacobi_ld<COH>(G + at);
+      vw[h][r] = jacobi_ld<COH>(W + at);
+    }
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int k = tid + JF * h;
 #pragma unroll
     for (int r = 0; r < 2 * JB; ++r) {
-      const int ri = row_of(r);
-      const bool in = ri >= 0 && k < N;
-      vg[h][r] = in ? G[(size_t)ri * N + k] : 0.;
-      vw[h][r] = in ? W[(size_t)ri * N + k] : 0.;
+      const bool in = row_of(r) >= 0 && k < N;
+      vg[h][r] = in ? vg[h][r] : 0.;
+      vw[h][r] = in ? vw[h][r] : 0.;
       if (k < ldt) tile[r * ldt + k] = vg[h][r];
     }
   }
-  if (tid == 0) nrot = 0;
+  if (tid == 0) { nrot = 0; worst = 0; }
   __syncthreads();
+#ifdef DDRL_CMAES_STAMPS
+  t1 = wall_clock64();
+#endif
   {
-    // S = A A^T: a 2 x 2 tile of S per thread (rows 2 tx, 2 tx + 1 against rows 2 ty, 2 ty + 1: four LDS reads feed four
-    // products), 64 tiles x 8 column slices; the slices are the low three bits of the lane, summed by butterfly
-    const int lane = tid & 63, sl = lane & 7, t64 = (tid >> 6) * 8 + (lane >> 3), tx = t64 >> 3, ty = t64 & 7;
-    const double *x0 = tile + (2 * tx) * ldt, *x1 = x0 + ldt, *y0 = tile + (2 * ty) * ldt, *y1 = y0 + ldt;
-    double a00 = 0., a01 = 0., a10 = 0., a11 = 0.;
-    for (int kk = sl; kk < N; kk += 8) {
-      const double p0 = x0[kk], p1 = x1[kk], q0 = y0[kk], q1 = y1[kk];
-      a00 += p0 * q0; a01 += p0 * q1; a10 += p1 * q0; a11 += p1 * q1;
+    // S = A A^T on the fp64 matrix cores: v_mfma_f64_16x16x4 sums 4 columns a step, A[i][k] on lane (i = l & 15, k = l >> 4) and
+    // B[k][j] = A[j][k] on the same lane -- one LDS read feeds both operands.  The 8 waves take the 4-column steps round robin
+    // into two accumulators each; their partial matrices meet in LDS (D[row = (l >> 4) + 4 v][col = l & 15] in register v).
+    const int lane = tid & 63, wv = tid >> 6;
+    const double *src = tile + (lane & 15) * ldt + (lane >> 4);
+    jf_f64x4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
+    const int nk = (N + 3) >> 2;
+    for (int ks = wv; ks < nk; ks += 16) {
+      const int k0 = 4 * ks + (lane >> 4), k1 = k0 + 32;
+      const double a0 = k0 < N ? src[4 * ks] : 0.;
+      const double a1 = ks + 8 < nk && k1 < N ? src[4 * ks + 32] : 0.;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
     }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-      a00 += __shfl_xor(a00, o); a01 += __shfl_xor(a01, o); a10 += __shfl_xor(a10, o); a11 += __shfl_xor(a11, o);
-    }
-    if (sl == 0) {
-      S[(2 * tx) * LS + 2 * ty] = a00; S[(2 * tx) * LS + 2 * ty + 1] = a01;
-      S[(2 * tx + 1) * LS + 2 * ty] = a10; S[(2 * tx + 1) * LS + 2 * ty + 1] = a11;
-    }
+    for (int v = 0; v < 4; ++v) part[wv * 256 + v * 64 + lane] = acc0[v] + acc1[v];
     if (tid < 256) T[tid] = (tid >> 4) == (tid & 15) ? 1. : 0.;
   }
   __syncthreads();
-  if (tid < 64) {                                   // ---- the 16 x 16 sweep, first wave only ----
-    const int yy = tid & 15, xg = tid >> 4;         // this lane's entries: rows 4 xg .. 4 xg + 3 of column yy
-    const int mm = 2 * JB - 1;
-    // Round 0 of a sweep rotates all 120 pairs of the 16 rows (15 steps: player 15 meets st, the others p <-> (2 st - p) mod 15);
-    // the other rounds only the 64 pairs ACROSS the two blocks (8 steps: row p of the first block meets row (p + st) mod 8 of
-    // the second) -- the pairs inside a block have had their turn in round 0, where every block plays (a block with a bye
-    // plays alone)
-    const bool full = step == 0;
-    auto partner_of = [&](int p, int st) {
-      if (!full) return p < JB ? JB + ((p + st) & (JB - 1)) : ((p - st) & (JB - 1));
-      if (p == mm) return st;
-      if (p == st) return mm;
-      int q = (2 * st - p) % mm;
-      return q < 0 ? q + mm : q;
-    };
-    const int nst = full ? 2 * JB - 1 : JB;
-    for (int st = 0; st < nst; ++st) {
-      if (tid < 2 * JB) {                           // lane p: the rotation of its own pair, its own row's coefficients
-        const int p = tid, q = partner_of(p, st), a = p < q ? p : q, c = p < q ? q : p;
-        const double al = S[a * LS + a], be = S[c * LS + c], ga = S[a * LS + c];
-        double co = 1., sn = 0.;
-        if (ga * ga > 1e-18 * (al * be)) {          // |g_a . g_c| > 1e-9 |g_a| |g_c|
-          const float zeta = (float)(be - al) / (2.f * (float)ga);
-          const float tf = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-          const double t = (double)tf, qq = 1. + t * t;
-          double r = (double)rsqrtf((float)qq);     // 1 / sqrt(1 + t^2): fp32 seed, two Newton steps
-          r = r * (1.5 - 0.5 * qq * r * r);
-          r = r * (1.5 - 0.5 * qq * r * r);
-          co = r; sn = r * t;
-          if (p == a) atomicAdd(&nrot, 1);
-        }
-        cc[p] = co; ss[p] = p == a ? -sn : sn;      // new_a = co a - sn c, new_c = sn a + co c
-      }
-      jacobi_wave_fence();
-      double sn4[4], tn4[4];
-      const int py = partner_of(yy, st);
-      const double cy = cc[yy], sy = ss[yy];
+  if (tid < 256) {
+    double sum = 0.;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int xx = 4 * xg + i, px = partner_of(xx, st);
-        const double cx = cc[xx], sx = ss[xx];
-        sn4[i] = cx * (cy * S[xx * LS + yy] + sy * S[xx * LS + py]) + sx * (cy * S[px * LS + yy] + sy * S[px * LS + py]);
-        tn4[i] = cx * T[xx * LT + yy] + sx * T[px * LT + yy];
-      }
-      jacobi_wave_fence();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { S[(4 * xg + i) * LS + yy] = sn4[i]; T[(4 * xg + i) * LT + yy] = tn4[i]; }
-      jacobi_wave_fence();
-    }
+    for (int w = 0; w < JF / 64; ++w) sum += part[w * 256 + tid];
+    S[(((tid & 63) >> 4) + 4 * (tid >> 6)) * LS + (tid & 15)] = sum;
   }
   __syncthreads();
+#ifdef DDRL_CMAES_STAMPS
+  t2 = wall_clock64();
+#endif
+  if (tid < 64) {                                   // ---- the 16 x 16 sweep, first wave only (round 0 of a sweep: all pairs) ----
+    if (step == 0) jacobi_tile_sweep<true>(S, T, tid, &nrot, &worst);
+    else jacobi_tile_sweep<false>(S, T, tid, &nrot, &worst);
+  }
+  __syncthreads();
+#ifdef DDRL_CMAES_STAMPS
+  t3 = wall_clock64();
+#endif
   if (nrot == 0) return;                            // uniform
-  if (tid == 0) atomicAdd(rotated, nrot);
+  if (tid == 0) { atomicAdd(rotated, nrot); atomicMax(rotated + 1, worst); }
   if (tid >= N) return;
 #pragma unroll 1
   for (int r = 0; r < 2 * JB; ++r) {                // (rolled: see cmaes_jacobi_block_round)
@@ -880,14 +935,74 @@ cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, i
       double og0 = 0., ow0 = 0., og1 = 0., ow1 = 0.;
 #pragma unroll
       for (int u = 0; u < 2 * JB; ++u) { const double t = tr[u]; og0 += t * vg[0][u]; ow0 += t * vw[0][u]; og1 += t * vg[1][u]; ow1 += t * vw[1][u]; }
-      G[(size_t)ri * N + tid] = og0;
-      W[(size_t)ri * N + tid] = ow0;
-      if (tid + JF < N) { G[(size_t)ri * N + tid + JF] = og1; W[(size_t)ri * N + tid + JF] = ow1; }
+      jacobi_st<COH>(G + (size_t)ri * N + tid, og0);
+      jacobi_st<COH>(W + (size_t)ri * N + tid, ow0);
+      if (tid + JF < N) { jacobi_st<COH>(G + (size_t)ri * N + tid + JF, og1); jacobi_st<COH>(W + (size_t)ri * N + tid + JF, ow1); }
     }
+  }
+#ifdef DDRL_CMAES_STAMPS
+  if (b == 1 && tid == 0) {
+    const long long t4 = wall_clock64();
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long t5 = wall_clock64();
+    rotated[2] = (int)(t1 - t0); rotated[3] = (int)(t2 - t1); rotated[4] = (int)(t3 - t2); rotated[5] = (int)(t4 - t3); rotated[6] = (int)(t5 - t4); rotated[7] = step;
+  }
+#endif
+}
+
+__global__ void __launch_bounds__(JF)
+cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, int ldt, int nb2, int step, int *__restrict__ rotated) {
+  extern __shared__ __align__(16) double jsm[];
+  jacobi_fast_round<false>(G, W, N, ldt, nb2, step, rotated, jsm);
+}
+
+// The WHOLE decomposition in one launch: the nb2 / 2 workgroups (at most 64, one per CU: all resident at once) loop over the sweeps'
+// rounds themselves and meet at a barrier in memory after each -- a round's kernel boundary (drain, cache write-back, dispatch:
+// ~7 us against ~12 us of work) and the host's look at the rotation count after every sweep go.  ctl[0] counts arrivals (never
+// reset inside a launch: round e waits for (e + 1) * workgroups), ctl[1] is raised by a workgroup that has waited longer than
+// JACOBI_BARRIER_TICKS of the 100 MHz clock (a workgroup that is not resident: another process holds CUs) -- every workgroup then
+// leaves at its next look, and the host carries on from that state with the launch-per-round path.  ctl[2] = sweeps done,
+// ctl[8 + 2 s], ctl[9 + 2 s]: sweep s's rotation count and worst ratio.  A workgroup's rows reach the others through agent-scope
+// stores and loads (no write-back / invalidation of a whole L2 at every barrier, which costs what the kernel boundary did): every
+// wave waits for its stores' acknowledgements before the workgroup's arrival is counted.
+#define JACOBI_MAX_SWEEPS 60
+#define JACOBI_CTL_INTS (8 + 2 * JACOBI_MAX_SWEEPS)
+#define JACOBI_BARRIER_TICKS 200000000ll          // 2 s
+__global__ void __launch_bounds__(JF)
+cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl) {
+  extern __shared__ __align__(16) double jsm[];
+  __shared__ int go;
+  const int tid = threadIdx.x, nwg = gridDim.x;
+  int epoch = 0;
+  for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+    int *rotated = ctl + 8 + 2 * sweep;
+    for (int step = 0; step < nb2 - 1; ++step) {
+      jacobi_fast_round<true>(G, W, N, ldt, nb2, step, rotated, jsm);
+      __builtin_amdgcn_s_waitcnt(0);                // this wave's stores have been acknowledged
+      __syncthreads();
+      if (tid == 0) {
+        ++epoch;
+        __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nwg) {
+          if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+          if (wall_clock64() - t0 > JACOBI_BARRIER_TICKS) { __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        go = ok;
+      }
+      __syncthreads();
+      if (!go) return;                              // uniform
+    }
+    // every workgroup reads the same count: all arrivals of the sweep's last round are behind it
+    const int rot = __hip_atomic_load(rotated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && tid == 0) ctl[2] = sweep + 1;
+    if (rot == 0) return;
   }
 }
 extern "C" size_t cmaes_jacobi_fast_lds(int ldt) {
-  return ((size_t)2 * JB * ldt + (2 * JB) * (2 * JB + 1) + (2 * JB) * (2 * JB) + 2 * (2 * JB)) * sizeof(double);
+  return ((size_t)2 * JB * ldt + (2 * JB) * (2 * JB + 1) + (2 * JB) * (2 * JB) + (JF / 64) * 256) * sizeof(double);
 }
 
 // lambda_i = g_i . w_i, D_i = sqrt(max(lambda_i, 0)), B[:, i] = w_i (fp32, the sampling GEMM's operand)
@@ -911,7 +1026,7 @@ static int device_eigen(ddrl_cmaes *h) {
   // players of a sweep's tournament: blocks of JB rows (eigen_block) or single rows
   const int nplayers = h->eigen_block ? (N + JB - 1) / JB : N, n2 = h->eigen_block ? (nplayers < 2 ? 2 : (nplayers + 1) / 2 * 2) : (N + 1) / 2 * 2;
   const int ldt = N | 1;                            // LDS row stride of the one-trip kernel (odd: the Gram sums' two row reads spread over the banks)
-  const bool fast = h->eigen_block && N <= 2 * JF && cmaes_jacobi_fast_lds(ldt) <= 150 * 1024;
+  const bool fast = h->eigen_block && N <= 2 * JF && cmaes_jacobi_fast_lds(ldt) <= 160 * 1024 - 64;
   if (fast) {
     static LdsConfig conf;
     HIPCHK(ddrl_set_lds(cmaes_jacobi_block_fast, cmaes_jacobi_fast_lds(ldt), conf));
@@ -947,20 +1062,59 @@ static int device_eigen(ddrl_cmaes *h) {
       if (g) (void)hipGraphDestroy(g);
       if (!ok) { h->sweep_graph = nullptr; h->sweep_graph_failed = true; (void)hipGetLastError(); }
     }
-    for (; sweeps < 60; ++sweeps) {
-      HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    bool persist = fast && h->eigen_persist;
+#ifdef DDRL_CMAES_STAMPS
+    persist = false;                                // the stamps are the launch-per-round kernel's
+#endif
+    static const bool trace = getenv("DDRL_CMAES_TRACE") != nullptr;
+    auto say = [&](int sweep, int rotations, int worst_bits) {
+      float w;
+      memcpy(&w, &worst_bits, 4);
+      fprintf(stderr, "[cmaes] gen %g sweep %d: %d rotations, worst (g_a.g_c)^2/(|g_a|^2|g_c|^2) %.3g\n", (double)h->gen, sweep, rotations, (double)w);
+    };
+    bool done = false;
+    if (persist) {                                  // every sweep in ONE launch (cmaes_jacobi_sweeps_fast)
+      static LdsConfig conf2;
+      HIPCHK(ddrl_set_lds(cmaes_jacobi_sweeps_fast, cmaes_jacobi_fast_lds(ldt), conf2));
+      std::vector<int> ctl(JACOBI_CTL_INTS);
+      HIPCHK(hipMemsetAsync(h->d_info, 0, ctl.size() * sizeof(int), h->stream));
+      hipLaunchKernelGGL(cmaes_jacobi_sweeps_fast, dim3(n2 / 2), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, h->d_info);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(ctl.data(), h->d_info, ctl.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (trace) for (int s2 = 0; s2 < ctl[2]; ++s2) say(s2, ctl[8 + 2 * s2], ctl[9 + 2 * s2]);
+      if (ctl[1]) {                                 // a workgroup was not resident within the barrier's bound: the matrices are a valid
+        h->eigen_persist_timeouts++;                // intermediate state (whole rounds only), the rounds below carry on from it
+        if (trace) fprintf(stderr, "[cmaes] the one-launch decomposition gave up at a barrier after %d sweeps: launch per round from here\n", ctl[2]);
+      } else if (ctl[2] > 0 && ctl[8 + 2 * (ctl[2] - 1)] == 0) {
+        sweeps = ctl[2] - 1;
+        done = true;
+      } else {
+        sweeps = JACOBI_MAX_SWEEPS;
+        done = true;
+      }
+    }
+    for (; !done && sweeps < JACOBI_MAX_SWEEPS; ++sweeps) {
+      HIPCHK(hipMemsetAsync(h->d_info, 0, 8 * sizeof(int), h->stream));
       if (h->sweep_graph) {
         HIPCHK(hipGraphLaunch(h->sweep_graph, h->stream));
       } else {
         for (int step = 0; step < n2 - 1; ++step) round(step);
       }
       HIPCHK(hipGetLastError());
-      int rotated = 0;
-      HIPCHK(hipMemcpyAsync(&rotated, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      HIPCHK(hipMemcpyAsync(info, h->d_info, sizeof(info), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
+      const int rotated = info[0];
+      if (trace) {
+        say(sweeps, rotated, info[1]);
+#ifdef DDRL_CMAES_STAMPS
+        fprintf(stderr, "[cmaes]   stamps (10 ns units) of workgroup 1, round %d: load %d gram %d sweep %d apply %d drain %d\n", info[7], info[2], info[3], info[4], info[5], info[6]);
+#endif
+      }
       if (rotated == 0) break;
     }
-    if (sweeps == 60) return ddrl_fail(DDRL_EHIP, "device_eigen: the Jacobi iteration did not converge in 60 sweeps");
+    if (sweeps >= JACOBI_MAX_SWEEPS) return ddrl_fail(DDRL_EHIP, "device_eigen: the Jacobi iteration did not converge in %d sweeps", JACOBI_MAX_SWEEPS);
   }
   h->eigen_sweeps = sweeps;
   h->eig_warm = 1;
@@ -1340,7 +1494,7 @@ extern "C" int ddrl_cmaes_get(ddrl_cmaes_t *h, const char *key, double *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return DDRL_OK;
   }
-  if (k == "eigen_sweeps") *out = h->eigen_sweeps; else if (k == "gen") *out = h->gen; else if (k == "lambda") *out = h->lambda; else if (k == "mu") *out = h->mu;
+  if (k == "eigen_sweeps") *out = h->eigen_sweeps; else if (k == "eigen_persist_timeouts") *out = h->eigen_persist_timeouts; else if (k == "gen") *out = h->gen; else if (k == "lambda") *out = h->lambda; else if (k == "mu") *out = h->mu;
   else if (k == "N" || k == "dim") *out = h->N; else if (k == "mueff") *out = h->mueff; else if (k == "cs") *out = h->cs;
   else if (k == "damps") *out = h->damps; else if (k == "ccumcov") *out = h->ccumcov; else if (k == "ccov") *out = h->ccov;
   else if (k == "mucov") *out = h->mucov; else if (k == "chiN") *out = h->chiN; else if (k == "modulo") *out = h->modulo;
@@ -1449,12 +1603,13 @@ extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value
       int rc;
       if ((rc = cm_alloc(h, &h->d_A, (size_t)h->N * h->N)) || (rc = cm_alloc(h, &h->d_ev, h->N)) ||
           (rc = cm_alloc(h, &h->d_W, (size_t)h->N * h->N)) || (rc = cm_alloc(h, &h->d_Cs, (size_t)h->N * h->N)) ||
-          (rc = cm_alloc(h, &h->d_info, 1))) return rc;
+          (rc = cm_alloc(h, &h->d_info, JACOBI_CTL_INTS))) return rc;
     }
     h->device_eigen = value != 0;
     h->eig_warm = 0;
     return DDRL_OK;
   }
+  if (std::string(key) == "eigen_persist") { h->eigen_persist = value != 0; return DDRL_OK; }  // 1 (default): one launch per decomposition; 0: one per round
   if (std::string(key) == "eigen_block") { h->eigen_block = value != 0; return DDRL_OK; }      // 1 (default): blocked rounds; 0: one row pair per workgroup
   return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);
 }

@@ -219,14 +219,17 @@ def test_device_eigen_throughput_mode():
     es.close()
 
 
-@pytest.mark.parametrize("block", [1, 0])
-@pytest.mark.parametrize("N", [1, 2, 7, 8, 9, 16, 17, 151, 631])
+@pytest.mark.parametrize("block", [2, 1, 0])
+@pytest.mark.parametrize("N", [1, 2, 7, 8, 9, 16, 17, 151, 631, 1000])
 def test_device_eigen_against_the_host_routines(N, block):
     """the same covariance through both eigensolvers: host Householder + QL (parity mode, c-cmaes' routines) and the device
     Jacobi kernels -- eigenvalues to 1e-10 relative, and both bases diagonalise C; odd, even and trivial sizes, sizes around the
-    8-row blocks of the blocked rounds (block = 1, the default: one block, one block and a ragged one, an odd number of blocks)
-    and the row-pair rounds (block = 0)"""
+    8-row blocks of the blocked rounds (one block, one block and a ragged one, an odd number of blocks), the largest sizes of the
+    one-trip round (N = 1000: nearly all of a CU's LDS).  block = 2, the default: every sweep in one launch with barriers in
+    memory; 1: one launch per blocked round; 0: the row-pair rounds"""
     from ddrl_amd.cmaes import Cmaes
+    if N == 1000 and block != 2:
+        pytest.skip("N = 1000 is here for the one-launch decomposition's LDS footprint")
     if N == 631 and block == 0:
         pytest.skip("the row-pair rounds at N = 631 are covered by the golden run; 630 launches per sweep")
     lam = max(8, 2 * N)
@@ -234,12 +237,15 @@ def test_device_eigen_against_the_host_routines(N, block):
     for dev in (0, 1):
         es = Cmaes(np.linspace(-0.5, 0.5, N) if N > 1 else np.zeros(1), np.linspace(0.2, 0.6, N) if N > 1 else [0.3], 7, lam)
         es.set_option("device_eigen", dev)
-        es.set_option("eigen_block", block)
+        es.set_option("eigen_block", int(block > 0))
+        es.set_option("eigen_persist", int(block == 2))
         for g in range(3):                          # three updates from the c-cmaes stream: identical C in both runs
             X = es.sample()
             if g == 1:
                 res.append((es.vec("C"), es.vec("B"), es.vec("D")))
             es.update(((X - 0.1) ** 2).sum(1) + np.arange(lam) * 1e-9)
+        if dev:
+            assert int(es.get("eigen_persist_timeouts")) == 0
         es.close()
     (C0, B0, D0), (C1, B1, D1) = res
     assert np.array_equal(C0, C1)                   # generation 1 sampled from the initial (diagonal) C in both
