@@ -758,18 +758,20 @@ cmaes_jacobi_block_round(double *__restrict__ G, double *__restrict__ W, int N, 
   }
 }
 
-// The same round for N <= 1024 (every policy of BASELINE.md): ONE trip to memory.  Thread k owns columns k and k + 512 of the 16 rows: it
-// fetches its 16 + 16 values of G and W at once (the rows were written by other workgroups in the previous round, so every
-// dependent access costs a device-level round trip -- the round above makes five of them in a row), parks the G values in LDS
-// for the Gram sums, and applies T to both from LDS / registers.  The 16 x 16 sweep runs in the first WAVE alone, ordered by
-// that wave's own LDS ordering instead of 45 workgroup barriers; the rotation's tangent is computed in fp32 (it only steers
-// the iteration), its cosine from the tangent in fp64 (a Newton-refined reciprocal square root: c^2 + s^2 = 1 to fp64 rounding).
+// The same round for N <= 1024 (every policy of BASELINE.md): ONE trip to memory.  A workgroup fetches its 16 rows of G and W at
+// once (the rows were written by other workgroups in the previous round, so every dependent access costs a device-level round
+// trip -- the round above makes five of them in a row) into the registers of its 8 waves, laid out as the fp64 matrix cores'
+// operand; parks the G values in LDS for the Gram matrix (v_mfma_f64_16x16x4, both operands from one LDS read); runs the 16 x 16
+// sweep in the first WAVE alone (its own LDS ordering instead of 45 workgroup barriers); and applies T to both matrices from the
+// registers, on the matrix cores again.  The rotation's tangent is computed in fp32 (it only steers the iteration), its cosine
+// from the tangent in fp64 (a Newton-refined reciprocal square root: c^2 + s^2 = 1 to fp64 rounding).
 __device__ __forceinline__ void jacobi_wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-#define JF 512       // threads of the one-trip round: two columns each
+#define JF 512       // threads of the one-trip round
+#define JFG_MAX 8    // column groups (of 16) a wave holds at most: 8 waves x 8 x 16 = 1024 columns (template parameter JFG: as many as N needs)
 typedef double jf_f64x4 __attribute__((ext_vector_type(4)));
 
 // One cyclic sweep on the 16 x 16 Gram matrix S (LDS), rotations accumulated in T (LDS); one wave.  FULL: all 120 pairs of the 16
@@ -838,14 +840,13 @@ __device__ __forceinline__ void jacobi_st(double *p, double v) {
   if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
 }
-template <bool COH>
+template <bool COH, int JFG>
 __device__ __forceinline__ void jacobi_fast_round(double *G, double *W, int N, int ldt, int nb2, int step, int *rotated, double *jsm) {
   double *tile = jsm;                               // [16][ldt]: the G rows
   double *S = tile + 2 * JB * ldt, *T = S + 2 * JB * (2 * JB + 1);     // [16][17], [16][16]
   double *part = T + 2 * JB * 2 * JB;               // [8 waves][256]: the waves' partial Gram matrices
   __shared__ int nrot, worst;
   const int tid = threadIdx.x, b = blockIdx.x, m = nb2 - 1, LS = 2 * JB + 1, LT = 2 * JB;
-  (void)LT;
   int P, Q;
   if (b == 0) { P = m; Q = step; }
   else { P = (step + b) % m; Q = (step - b + m) % m; }
@@ -856,29 +857,40 @@ __device__ __forceinline__ void jacobi_fast_round(double *G, double *W, int N, i
   long long t1 = 0, t2 = 0, t3 = 0;
 #endif
   auto row_of = [&](int r) { const int ri = r < JB ? P * JB + r : Q * JB + r - JB; return ri < N ? ri : -1; };
-  double vg[2][2 * JB], vw[2][2 * JB];              // columns tid and tid + JF of the 16 rows
-  // every fetch is issued before the first is waited for: the addresses are clamped into the matrix instead of branching round
-  // the load (a conditional load waits for its own data before the next is issued: 32 round trips in a row)
+  // The rows are held as the fp64 matrix core's B operand of the product T x rows: lane (lr = l >> 4, lc = l & 15) has element
+  // [row 4 ks + lr][column 16 cg + lc] of k-step ks of column group cg; wave wv owns the groups wv, wv + 8, ... (at most 8: N <= 1024).
+  // Every fetch is issued before the first is waited for: the addresses are clamped into the matrix instead of branching round
+  // the load (a conditional load waits for its own data before the next is issued: 32 round trips in a row).
+  const int lane = tid & 63, wv = tid >> 6, lr = lane >> 4, lc = lane & 15, ncg = (N + 15) >> 4;
+  double vg[JFG][4], vw[JFG][4];
+  int rix[4];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int k = tid + JF * h, kc = k < N ? k : N - 1;
+  for (int ks = 0; ks < 4; ++ks) rix[ks] = row_of(4 * ks + lr);
 #pragma unroll
-    for (int r = 0; r < 2 * JB; ++r) {
-      const int ri = row_of(r);
-      const size_t at = (size_t)(ri >= 0 ? ri : 0) * N + kc;
-      vg[h][r] = jacobi_ld<COH>(G + at);
-      vw[h][r] = jacobi_ld<COH>(W + at);
+  for (int g = 0; g < JFG; ++g) {
+    const int cg = wv + (JF / 64) * g;
+    if (cg < ncg) {                                 // (wave-uniform)
+      const int col = 16 * cg + lc, colc = col < N ? col : N - 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const size_t at = (size_t)(rix[ks] >= 0 ? rix[ks] : 0) * N + colc;
+        vg[g][ks] = jacobi_ld<COH>(G + at);
+        vw[g][ks] = jacobi_ld<COH>(W + at);
+      }
     }
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int k = tid + JF * h;
+  for (int g = 0; g < JFG; ++g) {
+    const int cg = wv + (JF / 64) * g;
+    if (cg < ncg) {
+      const int col = 16 * cg + lc;
 #pragma unroll
-    for (int r = 0; r < 2 * JB; ++r) {
-      const bool in = row_of(r) >= 0 && k < N;
-      vg[h][r] = in ? vg[h][r] : 0.;
-      vw[h][r] = in ? vw[h][r] : 0.;
-      if (k < ldt) tile[r * ldt + k] = vg[h][r];
+      for (int ks = 0; ks < 4; ++ks) {
+        const bool in = rix[ks] >= 0 && col < N;
+        vg[g][ks] = in ? vg[g][ks] : 0.;
+        vw[g][ks] = in ? vw[g][ks] : 0.;
+        if (col < N) tile[(4 * ks + lr) * ldt + col] = vg[g][ks];
+      }
     }
   }
   if (tid == 0) { nrot = 0; worst = 0; }
@@ -890,16 +902,17 @@ __device__ __forceinline__ void jacobi_fast_round(double *G, double *W, int N, i
     // S = A A^T on the fp64 matrix cores: v_mfma_f64_16x16x4 sums 4 columns a step, A[i][k] on lane (i = l & 15, k = l >> 4) and
     // B[k][j] = A[j][k] on the same lane -- one LDS read feeds both operands.  The 8 waves take the 4-column steps round robin
     // into two accumulators each; their partial matrices meet in LDS (D[row = (l >> 4) + 4 v][col = l & 15] in register v).
-    const int lane = tid & 63, wv = tid >> 6;
-    const double *src = tile + (lane & 15) * ldt + (lane >> 4);
+    const double *src = tile + lc * ldt + lr;
     jf_f64x4 acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
     const int nk = (N + 3) >> 2;
-    for (int ks = wv; ks < nk; ks += 16) {
-      const int k0 = 4 * ks + (lane >> 4), k1 = k0 + 32;
-      const double a0 = k0 < N ? src[4 * ks] : 0.;
-      const double a1 = ks + 8 < nk && k1 < N ? src[4 * ks + 32] : 0.;
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+    for (int ks = wv; ks < nk; ks += 32) {          // four steps' operands are read before the first product waits for its own
+      double av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[u] = 4 * (ks + 8 * u) + lr < N ? src[4 * (ks + 8 * u)] : 0.;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], av[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], av[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], av[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], av[3], acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) part[wv * 256 + v * 64 + lane] = acc0[v] + acc1[v];
@@ -925,21 +938,35 @@ __device__ __forceinline__ void jacobi_fast_round(double *G, double *W, int N, i
   t3 = wall_clock64();
 #endif
   if (nrot == 0) return;                            // uniform
-  if (tid == 0) { atomicAdd(rotated, nrot); atomicMax(rotated + 1, worst); }
-  if (tid >= N) return;
-#pragma unroll 1
-  for (int r = 0; r < 2 * JB; ++r) {                // (rolled: see cmaes_jacobi_block_round)
-    const int ri = row_of(r);
-    if (ri >= 0) {
-      const double *tr = T + r * LT;
-      double og0 = 0., ow0 = 0., og1 = 0., ow1 = 0.;
+  // rows <- T x rows, G and W alike, on the matrix cores: A[i][k] = T[i][4 ks + k] on lane (i = lc, k = lr), four k-steps per
+  // column group; the result has row lr + 4 v, column lc in register v
+  double ta[4];
 #pragma unroll
-      for (int u = 0; u < 2 * JB; ++u) { const double t = tr[u]; og0 += t * vg[0][u]; ow0 += t * vw[0][u]; og1 += t * vg[1][u]; ow1 += t * vw[1][u]; }
-      jacobi_st<COH>(G + (size_t)ri * N + tid, og0);
-      jacobi_st<COH>(W + (size_t)ri * N + tid, ow0);
-      if (tid + JF < N) { jacobi_st<COH>(G + (size_t)ri * N + tid + JF, og1); jacobi_st<COH>(W + (size_t)ri * N + tid + JF, ow1); }
+  for (int ks = 0; ks < 4; ++ks) ta[ks] = T[lc * LT + 4 * ks + lr];
+  int rox[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) rox[v] = row_of(lr + 4 * v);
+#pragma unroll
+  for (int g = 0; g < JFG; ++g) {
+    const int cg = wv + (JF / 64) * g;
+    if (cg < ncg) {
+      jf_f64x4 og = {0., 0., 0., 0.}, ow = {0., 0., 0., 0.};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        og = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks], vg[g][ks], og, 0, 0, 0);
+        ow = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[ks], vw[g][ks], ow, 0, 0, 0);
+      }
+      const int col = 16 * cg + lc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (rox[v] >= 0 && col < N) {
+          jacobi_st<COH>(G + (size_t)rox[v] * N + col, og[v]);
+          jacobi_st<COH>(W + (size_t)rox[v] * N + col, ow[v]);
+        }
     }
   }
+  // (after the stores: the compiler waits for these two before whatever follows them, and this is the wave the others wait for)
+  if (tid == 0) { atomicAdd(rotated, nrot); atomicMax(rotated + 1, worst); }
 #ifdef DDRL_CMAES_STAMPS
   if (b == 1 && tid == 0) {
     const long long t4 = wall_clock64();
@@ -950,10 +977,11 @@ __device__ __forceinline__ void jacobi_fast_round(double *G, double *W, int N, i
 #endif
 }
 
+template <int JFG>
 __global__ void __launch_bounds__(JF)
 cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, int ldt, int nb2, int step, int *__restrict__ rotated) {
   extern __shared__ __align__(16) double jsm[];
-  jacobi_fast_round<false>(G, W, N, ldt, nb2, step, rotated, jsm);
+  jacobi_fast_round<false, JFG>(G, W, N, ldt, nb2, step, rotated, jsm);
 }
 
 // The WHOLE decomposition in one launch: the nb2 / 2 workgroups (at most 64, one per CU: all resident at once) loop over the sweeps'
@@ -968,6 +996,8 @@ cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, i
 #define JACOBI_MAX_SWEEPS 60
 #define JACOBI_CTL_INTS (8 + 2 * JACOBI_MAX_SWEEPS)
 #define JACOBI_BARRIER_TICKS 200000000ll          // 2 s
+#define JACOBI_PERSIST_JFG 5                      // widest instantiation of the one-launch kernel (N <= 640): beyond, its loop's registers spill
+template <int JFG>
 __global__ void __launch_bounds__(JF)
 cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl) {
   extern __shared__ __align__(16) double jsm[];
@@ -977,7 +1007,7 @@ cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl
   for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
     int *rotated = ctl + 8 + 2 * sweep;
     for (int step = 0; step < nb2 - 1; ++step) {
-      jacobi_fast_round<true>(G, W, N, ldt, nb2, step, rotated, jsm);
+      jacobi_fast_round<true, JFG>(G, W, N, ldt, nb2, step, rotated, jsm);
       __builtin_amdgcn_s_waitcnt(0);                // this wave's stores have been acknowledged
       __syncthreads();
       if (tid == 0) {
@@ -1027,12 +1057,20 @@ static int device_eigen(ddrl_cmaes *h) {
   const int nplayers = h->eigen_block ? (N + JB - 1) / JB : N, n2 = h->eigen_block ? (nplayers < 2 ? 2 : (nplayers + 1) / 2 * 2) : (N + 1) / 2 * 2;
   const int ldt = N | 1;                            // LDS row stride of the one-trip kernel (odd: the Gram sums' two row reads spread over the banks)
   const bool fast = h->eigen_block && N <= 2 * JF && cmaes_jacobi_fast_lds(ldt) <= 160 * 1024 - 64;
+  // the one-trip kernels are compiled per number of 16-column groups a wave holds (their registers): 1 .. JFG_MAX
+  const int jfg = ((N + 15) / 16 + JF / 64 - 1) / (JF / 64);
+  typedef void (*round_fn)(double *, double *, int, int, int, int, int *);
+  typedef void (*sweeps_fn)(double *, double *, int, int, int, int *);
+  static const round_fn round_k[JFG_MAX] = {cmaes_jacobi_block_fast<1>, cmaes_jacobi_block_fast<2>, cmaes_jacobi_block_fast<3>, cmaes_jacobi_block_fast<4>,
+                                            cmaes_jacobi_block_fast<5>, cmaes_jacobi_block_fast<6>, cmaes_jacobi_block_fast<7>, cmaes_jacobi_block_fast<8>};
+  static const sweeps_fn sweeps_k[JACOBI_PERSIST_JFG] = {cmaes_jacobi_sweeps_fast<1>, cmaes_jacobi_sweeps_fast<2>, cmaes_jacobi_sweeps_fast<3>,
+                                                         cmaes_jacobi_sweeps_fast<4>, cmaes_jacobi_sweeps_fast<5>};
   if (fast) {
-    static LdsConfig conf;
-    HIPCHK(ddrl_set_lds(cmaes_jacobi_block_fast, cmaes_jacobi_fast_lds(ldt), conf));
+    static LdsConfig conf[JFG_MAX];
+    HIPCHK(ddrl_set_lds(round_k[jfg - 1], cmaes_jacobi_fast_lds(ldt), conf[jfg - 1]));
   }
   auto round = [&](int step) {
-    if (fast) hipLaunchKernelGGL(cmaes_jacobi_block_fast, dim3(n2 / 2), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, step, h->d_info);
+    if (fast) hipLaunchKernelGGL(round_k[jfg - 1], dim3(n2 / 2), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, step, h->d_info);
     else if (h->eigen_block) hipLaunchKernelGGL(cmaes_jacobi_block_round, dim3(n2 / 2), dim3(JT), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
     else hipLaunchKernelGGL(cmaes_jacobi_round, dim3(n2 / 2), dim3(256), 0, h->stream, h->d_A, h->d_W, N, n2, step, h->d_info);
   };
@@ -1062,7 +1100,7 @@ static int device_eigen(ddrl_cmaes *h) {
       if (g) (void)hipGraphDestroy(g);
       if (!ok) { h->sweep_graph = nullptr; h->sweep_graph_failed = true; (void)hipGetLastError(); }
     }
-    bool persist = fast && h->eigen_persist;
+    bool persist = fast && h->eigen_persist && jfg <= JACOBI_PERSIST_JFG;
 #ifdef DDRL_CMAES_STAMPS
     persist = false;                                // the stamps are the launch-per-round kernel's
 #endif
@@ -1074,11 +1112,11 @@ static int device_eigen(ddrl_cmaes *h) {
     };
     bool done = false;
     if (persist) {                                  // every sweep in ONE launch (cmaes_jacobi_sweeps_fast)
-      static LdsConfig conf2;
-      HIPCHK(ddrl_set_lds(cmaes_jacobi_sweeps_fast, cmaes_jacobi_fast_lds(ldt), conf2));
+      static LdsConfig conf2[JACOBI_PERSIST_JFG];
+      HIPCHK(ddrl_set_lds(sweeps_k[jfg - 1], cmaes_jacobi_fast_lds(ldt), conf2[jfg - 1]));
       std::vector<int> ctl(JACOBI_CTL_INTS);
       HIPCHK(hipMemsetAsync(h->d_info, 0, ctl.size() * sizeof(int), h->stream));
-      hipLaunchKernelGGL(cmaes_jacobi_sweeps_fast, dim3(n2 / 2), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, h->d_info);
+      hipLaunchKernelGGL(sweeps_k[jfg - 1], dim3(n2 / 2), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, h->d_info);
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(ctl.data(), h->d_info, ctl.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
