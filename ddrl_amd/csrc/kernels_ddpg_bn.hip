@@ -85,10 +85,20 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   float *g_a = P.gpart_a + (size_t)agent * na.stride(), *g_q = P.gpart_q + (size_t)agent * nq.stride();
   const int tmode = P.test_net ? BN_TEST : BN_TRAIN;
   auto none = [](int, int, float) {};
-  auto actions_in = [&](const float *src) {                // actions into the critic's input tile
-    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+  // Developmental gates (DODevMLP.hpp:246-316): the state gates are gather_tile's; the action layer sits behind the actor's last
+  // layer (behind its output tower) and behind the critic's input.  Per-dimension factors only: the host refuses the per-sample
+  // Bernoulli mode on nets with towers.
+  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  auto actions_in = [&](float *src) {                      // actions into the critic's input tile: the actor's output gate (kept in
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {     // src: what the actor returned), then the critic's action-input gate
       const int row = e / A, col = e - row * A;
-      M.xc[row * ldxc + S + col] = src[row * lda + col];
+      float a = src[row * lda + col];
+      if (agate) {
+        a *= agate[col];
+        src[row * lda + col] = a;
+        a *= agate[col];
+      }
+      M.xc[row * ldxc + S + col] = a;
     }
   };
 
@@ -141,7 +151,7 @@ ddpg_update_bn_kernel(const DdpgParams P) {
     __syncthreads();
   }
   fwd_net_bn(na, na.L(), w_a, BN_TRAIN, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);   // pi = ann(s)
-  const float *acts = adapt ? Z.pa : M.topa;
+  float *acts = adapt ? Z.pa : M.topa;
   actions_in(acts);
   __syncthreads();
   fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);   // Q(s, pi(s)), new critic
@@ -153,6 +163,8 @@ ddpg_update_bn_kernel(const DdpgParams P) {
     const bool top_tower = na.bn(na.L());
     float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
     auto store = [=](int row, int h, float diff) {
+      const float gt = agate ? agate[h] : 1.f;
+      diff *= gt;                                                        // the critic's action-input gate
       if (inverting) {                                                   // :432-450, on the actions the critic saw
         const float out = acts[row * lda + h];
         if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
@@ -160,9 +172,12 @@ ddpg_update_bn_kernel(const DdpgParams P) {
       }
       if (row >= B) diff = 0.f;
       if (dact_out && row < B) dact_out[row * A + h] = diff;
-      // the actor's output layer: its own blob values feed the activation's backward; under an output tower the tower's
-      // backward comes first (bwd_net_bn)
-      topa[row * lda + h] = top_tower ? diff : act_bwd(out_act, topa[row * lda + h], diff);
+      diff *= gt;                                                        // the actor's output gate
+      // the actor's output layer: its own blob values feed the activation's backward (the ungated ones: without bn_adapt the
+      // gate was applied in place); under an output tower the tower's backward comes first (bwd_net_bn)
+      float out = topa[row * lda + h];
+      if (!adapt && gt != 0.f) out /= gt;
+      topa[row * lda + h] = top_tower ? diff : act_bwd(out_act, out, diff);
     };
     bwd_net_bn<DW_NONE>(nq, w_q, nullptr, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, S, A, store, wave, lane, tid);
   }
@@ -199,7 +214,8 @@ extern "C" hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st)
 // a TEST-phase copy returns, MLP.hpp:284-338, 531-579; no state changes)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DDRL_NTHREADS)
-net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out, int n, int ldh) {
+net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out, int n, int ldh,
+                      const float *__restrict__ sgate, int S, const float *__restrict__ agate, int A, int gate_out) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,7 +225,10 @@ net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float
   const float *xin = X + (size_t)agent * n * d0;
   for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
     const int row = e / ldx, col = e - row * ldx;
-    x[e] = (row < rows && col < d0) ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
+    float v = (row < rows && col < d0) ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
+    if (sgate && col < S) v *= sgate[(size_t)agent * S + col];                          // per-dimension gates (no Bernoulli mode with towers)
+    else if (agate && !gate_out && col >= S && col < S + A) v *= agate[(size_t)agent * A + col - S];
+    x[e] = v;
   }
   __syncthreads();
   const BnBufs nokeep = {nullptr, nullptr, nullptr, nullptr};
@@ -218,17 +237,18 @@ net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float
   float *o = out + (size_t)agent * n * dl;
   for (int e = tid; e < DDRL_MB * dl; e += DDRL_NTHREADS) {
     const int row = e / dl, col = e - row * dl;
-    if (row < rows) o[(size_t)(row0 + row) * dl + col] = top[row * ldt + col];
+    if (row < rows) o[(size_t)(row0 + row) * dl + col] = top[row * ldt + col] * (agate && gate_out ? agate[(size_t)agent * A + col] : 1.f);
   }
 }
 
-extern "C" hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G, hipStream_t st) {
+extern "C" hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
+                                            const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
   static LdsConfig conf;
   int ldh = 4;
   for (int l = 1; l < nd->L_; ++l) ldh = std::max(ldh, nd->ld_[l]);
   const size_t lds = ((size_t)(nd->L_ - 1) * DDRL_MB * ldh + (size_t)DDRL_MB * (nd->ld_[0] + nd->ld_[nd->L_])) * sizeof(float);
   hipError_t e = ddrl_set_lds(net_forward_bn_kernel, lds, conf);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(net_forward_bn_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out, n, ldh);
+  hipLaunchKernelGGL(net_forward_bn_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out, n, ldh, sgate, S, agate, A, gate_out);
   return hipGetLastError();
 }

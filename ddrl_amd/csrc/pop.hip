@@ -35,7 +35,8 @@ int ddpg_update_loop8_ok(const DdpgParams *P);
 hipError_t ddpg_update_loop8_launch(const DdpgParams *P, hipStream_t st);
 hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st);
 size_t ddpg_update_bn_lds_bytes(const DdpgParams *P);
-hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G, hipStream_t st);
+hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
+                                 const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
 hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, float *actions,
                         const float *in_gate, const float *out_gate, const GateMode *gm, int G, hipStream_t st);
 hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
@@ -641,7 +642,8 @@ extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float
   const GateMode gm = next_draw(h, 1);
   hipError_t e = hipMemcpyAsync(dx, x, G * n * d0 * sizeof(float), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess)
-    e = towers ? net_forward_bn_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, h->stream) :
+    e = towers ? net_forward_bn_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, sg, h->cfg.nb_sensors, ag, h->cfg.nb_motors,
+                                       actor ? 1 : 0, h->stream) :
         wide ? net_forward_wide_launch(&t->nd, net_weights(h, net), dx, dout, dscr, n, h->G, sg, h->cfg.nb_sensors, ag,
                                        h->cfg.nb_motors, actor ? 1 : 0, &gm, h->stream)
              : net_forward_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, sg, h->cfg.nb_sensors, ag, h->cfg.nb_motors,
@@ -884,7 +886,6 @@ extern "C" int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const
   int rc = set_device(h);
   if (rc) return rc;
   if (!state_gate && !action_gate) { h->gates_on = false; h->gate_w_s.clear(); h->gate_w_a.clear(); return DDRL_OK; }
-  if (h->bn) return ddrl_fail(DDRL_EINVAL, "developmental gates on BatchNorm nets are not supported");
   const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors;
   if (!h->d_sgate) {
     if ((rc = dalloc(h, &h->d_sgate, G * S))) return rc;

@@ -67,7 +67,7 @@ typedef struct {
   int    nstep_return;             /* agent.nstep_return (DeepQNAg.hpp:360-373, 394-402) */
   int    batch_norm_actor, batch_norm_critic;  /* agent.batch_norm_actor / _critic: the bit-field of MLP.hpp:53-79 (bit 0 Scale bias,
                                                 * bit 1 Scale, bits 2-4 where the towers sit); != 0: mini_batch_size <= 64,
-                                                * widths <= 128, no EWC / gates / TD3 (kernels_ddpg_bn.hip) */
+                                                * widths <= 128, no EWC / Bernoulli gates / TD3 (kernels_ddpg_bn.hip) */
   double gamma;                    /* agent.gamma */
   double tau_soft_update, alpha_a, alpha_v, decay_v;
   /* [devnn] EWC keys (common/include/nn/DODevMLP.hpp:172-190); ewc < 0 disables */
@@ -191,7 +191,8 @@ int ddrl_pop_ddpg_last(ddrl_pop_t *h, int32_t *idx, float *loss, float *q_target
  * (applied to the state input of every net) and per action dimension (applied to the actor's output
  * and to the critic's action input), shared by the agent's nets, not learned (heuristic != 0).
  * state_gate [G x S], action_gate [G x A]; either may be NULL (= ones); both NULL = gates off.  The
- * schedule (DODevMLP::inform, :420-470) stays with the caller.  Applies to DDPG and NFAC handles. */
+ * schedule (DODevMLP::inform, :420-470) stays with the caller.  Applies to DDPG and NFAC handles, nets with BatchNorm towers
+ * included (the state gate ahead of an input tower, the action gate behind the actor's output tower). */
 int ddrl_pop_set_gates(ddrl_pop_t *h, const double *state_gate, const double *action_gate);
 /* the gates in force, [G x nb_sensors] / [G x nb_motors] (all ones when off); either may be NULL */
 int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate);
@@ -202,7 +203,7 @@ int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate);
  * pass of every layer instance draws its own mask, a backward pass re-creates its forward pass's mask (counter-based
  * generator keyed on seed / pass / agent / layer instance / row / dimension: the fork's generator is unknown, only the
  * pass rates are pinned).  Served by every DDPG / TD3 update path (one-tile, chunked, layer-by-layer), NFAC, infer and
- * forward_batch; DDRL_EINVAL together with BatchNorm towers. */
+ * forward_batch; DDRL_EINVAL together with BatchNorm towers (the per-dimension gates of ddrl_pop_set_gates are served there). */
 int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed);
 /* DODevMLP's view of a net's parameters: after DODevMLP::exploit (DODevMLP.hpp:216-401) the gate weights are blobs of the
  * net, so number_of_parameters / copyWeightsTo / copyWeightsFrom (MLP.hpp:610-676) count and carry them:

@@ -337,8 +337,10 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
   int type = n->out_act;
   double *dtop = NULL;
   if (n->bn_rank[L]) {
+    /* the output gate sits behind the tower (DODevMLP.hpp:246-316: behind the net's last layer): its backward comes first */
     dtop = (double *)malloc(sizeof(double) * B * dl);
-    memcpy(dtop, dout, sizeof(double) * B * dl);
+    for (int i = 0; i < B * dl; ++i)
+      dtop[i] = dout[i] * (n->row_out ? n->row_out[i] : n->out_gate ? n->out_gate[i % dl] : 1.);
     bn_backward(n, L, B, dtop);
     dout = dtop;
   }
@@ -347,7 +349,7 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
     double y = n->act[L][i];
     if (n->row_out || n->out_gate) {
       double gte = n->row_out ? n->row_out[i] : n->out_gate[i % dl];
-      d *= gte;
+      if (!n->bn_rank[L]) d *= gte;
       /* a gated-off output is 0; the activation derivative needs the pre-gate value, which for a
        * 0 gate is irrelevant since d == 0 */
       if (gte != 0.) y /= gte;

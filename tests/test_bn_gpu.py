@@ -253,8 +253,67 @@ def test_reference_ini_loads_and_updates(tmp_path):
         assert np.all(np.isfinite(w)) and not np.array_equal(w, w0[n])
     act = pop.infer(np.random.RandomState(1).uniform(-1, 1, (4, 18)).astype(np.float32))
     assert np.all(np.isfinite(act))
-    with pytest.raises(ddrl_amd.DdrlError, match="gates"):
-        pop.set_gates(np.ones((4, 18)), np.ones((4, 6)))
+    pop.set_gates(np.ones((4, 18)), np.ones((4, 6)))                     # per-dimension gates are served on tower nets ...
+    with pytest.raises(ddrl_amd.DdrlError, match="probabilistic gates"):   # ... the per-sample Bernoulli mode is not
+        pop.set_gate_mode(1, 0, 1, 0, 7)
+    pop.close()
+
+
+@pytest.mark.parametrize("bna,bnq,binary,adapt,inverting", [(14, 11, True, 0, False), (14, 11, False, 0, True), (7, 12, False, 1, True),
+                                                             (22, 19, True, 1, False), (0, 7, False, 0, False), (6, 0, True, 0, True)])
+def test_ddpg_update_with_towers_and_gates(ora, bna, bnq, binary, adapt, inverting):
+    """Developmental gates (DODevMLP.hpp:246-316) on nets with towers, the layouts CaffeUtest.cpp:619-624 runs its Developmental
+    tests over: the state gate ahead of the input tower, the action gate behind the actor's output tower and ahead of the
+    critic's input tower.  Per-dimension factors (binary: the deterministic layer's 0 / 1; fractional: any w), with and
+    without bn_adapt (the TEST-phase copy's actions are gated like the actor's) and inverting gradients; three teacher-forced
+    updates, forward_batch on all four nets and the acting copy's inference against the oracle with the same gates."""
+    G, B, S, A = 3, 64, 18, 6
+    pop, agents, frozen = make_bn_pair(ora, bna, bnq, G=G, seed=bna + bnq + 3, bn_adapt=adapt, inverting_grad=inverting)
+    rng = np.random.RandomState(bna * 31 + bnq)
+    if binary:
+        sg = (rng.uniform(0, 1, (G, S)) < 0.6).astype(np.float64)
+        ag = (rng.uniform(0, 1, (G, A)) < 0.6).astype(np.float64)
+        ag[:, 0] = 1.0
+    else:
+        sg = np.round(rng.uniform(0.2, 1, (G, S)), 2).astype(np.float32).astype(np.float64)
+        ag = np.round(rng.uniform(0.2, 1, (G, A)), 2).astype(np.float32).astype(np.float64)
+    pop.set_gates(sg, ag)
+    for g, a in enumerate(agents):
+        for net in (a.ann, a.ann_target, a.ann_testing):
+            net.set_gates(sg[g], ag[g])
+        cin = np.concatenate([sg[g], ag[g]])
+        a.qnn.set_gates(cin, None); a.qnn_target.set_gates(cin, None)
+    noise = critic_kills_action_gradient(bnq)
+    for upd in range(3):
+        ws_prev = sync(pop, agents)
+        idx = np.random.RandomState(15 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        pop.update(idx)
+        last = pop.last()
+        for g, a in enumerate(agents):
+            loss, _ = a.update(idx[g])
+            qt, dact = a.last()
+            assert rel_err(last["q_targets"][g], qt) <= TOL, (upd, g, rel_err(last["q_targets"][g], qt))
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            if noise:
+                assert np.max(np.abs(dact)) <= 1e-12 and np.max(np.abs(last["dact"][g])) <= 1e-4
+            else:
+                assert rel_err(last["dact"][g], dact) <= TOL, (upd, g, rel_err(last["dact"][g], dact))
+                assert np.all(last["dact"][g][:, ag[g] == 0] == 0)
+        check_update(pop, agents, frozen, ws_prev, actor_noise=noise)
+    sync(pop, agents)
+    x = np.random.RandomState(4).uniform(-1, 1, (G, 40, S + A)).astype(np.float32)
+    for net in range(4):
+        xin = x if net in (1, 3) else np.ascontiguousarray(x[:, :, :S])
+        out = pop.forward_batch(net, xin)
+        for g, a in enumerate(agents):
+            ref = a.nets[net].clone(test=True).forward(xin[g].astype(np.float64))       # (a clone keeps the gates)
+            assert rel_err(out[g], ref) <= TOL, ("forward_batch", net, g, rel_err(out[g], ref))
+            if net in (0, 2):
+                assert np.all(out[g][:, ag[g] == 0] == 0)
+    st = np.ascontiguousarray(x[:, 0, :S])
+    act = pop.infer(st)
+    for g, a in enumerate(agents):
+        assert rel_err(act[g], a.ann_testing.forward(st[g].astype(np.float64))[0]) <= TOL
     pop.close()
 
 
