@@ -48,15 +48,16 @@ __device__ __forceinline__ BnLds bn_carve(float *p, const DdpgParams &P, int ldq
 }
 
 // Adam + L2 (+ the soft target update) over the learnable part of an agent's block, gradients from gout
-__device__ __forceinline__ void bn_apply(const NetDesc &nd, const OptCtx o, const float *__restrict__ gout, int tid) {
+template <bool EWC>
+__device__ __forceinline__ void bn_apply(const NetDesc &nd, const OptCtx &o, const float *__restrict__ gout, int tid) {
   for (int i = tid * 4; i < nd.stride(); i += DDRL_NTHREADS * 4) {
     bool stats = false;
     for (int r = 0; r <= nd.L(); ++r)
       stats = stats || (nd.bn(r) && i >= nd.bn_off(r) && i < nd.bn_off(r) + nd.bn_stats_floats(r));
     if (stats) continue;
     OptRegs rg;
-    opt_load4<false, true, false>(o, i, rg);
-    opt_step4<false, true, false>(o, i, *(const f32x4 *)(gout + i), rg, true);
+    opt_load4<EWC, true, false>(o, i, rg);
+    opt_step4<EWC, true, false>(o, i, *(const f32x4 *)(gout + i), rg, true);
   }
 }
 // MLP::soft_update over the statistics blobs (they are in params(), MLP.hpp:441-451)
@@ -66,6 +67,7 @@ __device__ __forceinline__ void bn_soft_stats(const NetDesc &nd, const float *__
       for (int i = nd.bn_off(r) + tid; i < nd.bn_off(r) + nd.bn_stats_floats(r); i += DDRL_NTHREADS) wt[i] = tau * w[i] + omtau * wt[i];
 }
 
+template <bool EWC_A, bool EWC_Q>
 __global__ void __launch_bounds__(DDRL_NTHREADS)
 ddpg_update_bn_kernel(const DdpgParams P) {
   extern __shared__ __align__(16) float lds[];
@@ -131,10 +133,12 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   __syncthreads();
   bwd_net_bn<DW_STORE>(nq, w_q, g_q, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, 0, 0, none, wave, lane, tid);
   __syncthreads();                                          // (workgroup-scope fence: the sweep reads other threads' gradient stores)
-  {
-    OptCtx oq = make_opt<false>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B, 0);
+  // EWC (DODevMLP.hpp:636-707: Fisher average of the squared gradients, penalty towards the previous task's parameters) rides
+  // in the optimiser sweep as on the tower-free path; a tower's statistics take no part (lr_mult 0: not in the EWC vectors)
+  {                                                         // (EWC_Q: agent.ewc >= 0 with ewc_for_critic)
+    OptCtx oq = make_opt<EWC_Q>(P, P.sq, nq.stride(), agent, tau, omtau, (float)B, 0);
     oq.handoff = 0;
-    bn_apply(nq, oq, g_q, tid);
+    bn_apply<EWC_Q>(nq, oq, g_q, tid);
   }
   __syncthreads();
   // ---- actor update (:411-459) ----
@@ -188,24 +192,32 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   bwd_net_bn<DW_STORE>(na, w_a, g_a, false, B, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, 0, 0, none, wave, lane, tid);
   __syncthreads();
   {
-    OptCtx oa = make_opt<false>(P, P.sa, na.stride(), agent, tau, omtau, (float)B, 0);
+    OptCtx oa = make_opt<EWC_A>(P, P.sa, na.stride(), agent, tau, omtau, (float)B, 0);
     oa.handoff = 0;
-    bn_apply(na, oa, g_a, tid);
+    bn_apply<EWC_A>(na, oa, g_a, tid);
   }
   // ---- soft updates of the statistics (:462-463: after both nets have stepped and the critic's second forward) ----
   bn_soft_stats(nq, w_q, w_qt, tau, omtau, tid);
   bn_soft_stats(na, w_a, w_at, tau, omtau, tid);
-  if (tid == 0) { P.sq.iter[agent] += 1; P.sa.iter[agent] += 1; }
+  if (tid == 0) {
+    P.sq.iter[agent] += 1; P.sa.iter[agent] += 1;
+    if (EWC_Q) P.sq.fisher_nbr[agent] = P.sq.fisher_nbr[agent] * P.fisher_beta + (float)B;     // DODevMLP.hpp:656
+    if (EWC_A) P.sa.fisher_nbr[agent] = P.sa.fisher_nbr[agent] * P.fisher_beta + (float)B;
+  }
 }
 
 extern "C" size_t ddpg_update_bn_lds_bytes(const DdpgParams *P) { return bn_lds_floats(*P) * sizeof(float); }
 
 extern "C" hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st) {
-  static LdsConfig configured;
+  static LdsConfig configured[3];
   const size_t lds = ddpg_update_bn_lds_bytes(P);
-  hipError_t e = ddrl_set_lds(ddpg_update_bn_kernel, lds, configured);
+  // the actor carries EWC whenever it is on, the critic with ewc_for_critic (DODevMLP.hpp:714-720)
+  const int which = P->sa.fisher ? (P->sq.fisher ? 2 : 1) : 0;
+  void (*k)(const DdpgParams) = which == 2 ? ddpg_update_bn_kernel<true, true> : which == 1 ? ddpg_update_bn_kernel<true, false>
+                                                                                            : ddpg_update_bn_kernel<false, false>;
+  hipError_t e = ddrl_set_lds(k, lds, configured[which]);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ddpg_update_bn_kernel, dim3(P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+  hipLaunchKernelGGL(k, dim3(P->G), dim3(DDRL_NTHREADS), lds, st, *P);
   return hipGetLastError();
 }
 

@@ -219,7 +219,7 @@ load_flat_kernel(NetDesc nd, float *__restrict__ w, const float *__restrict__ fl
 // ewc_setup (DODevMLP.hpp:604-633): wstar <- best; w <- wstar; fhat <- (F / nbr) / max(F / nbr);
 // F <- 0 (the reference drops the vector: fisher = nullptr), nbr <- 0
 extern "C" __global__ void __launch_bounds__(256)
-ewc_setup_kernel(float *__restrict__ w, const float *__restrict__ best, float *__restrict__ wstar,
+ewc_setup_kernel(const NetDesc nd, float *__restrict__ w, const float *__restrict__ best, float *__restrict__ wstar,
                  float *__restrict__ fisher, float *__restrict__ fhat, float *__restrict__ fisher_nbr,
                  int stride, const uint8_t *__restrict__ flag) {
   __shared__ float red[256];
@@ -231,7 +231,12 @@ ewc_setup_kernel(float *__restrict__ w, const float *__restrict__ best, float *_
   for (int i = t; i < stride; i += 256) {
     const float b = best[off + i];
     wstar[off + i] = b;
-    w[off + i] = b;
+    // copyWeightsFrom(best, ignore_null_lr = true) (DODevMLP.hpp:616): a tower's running statistics (lr_mult 0) are not in the
+    // vector and stay as they are
+    bool stats = false;
+    for (int r = 0; r <= nd.L(); ++r)
+      stats = stats || (nd.bn(r) && i >= nd.bn_off(r) && i < nd.bn_off(r) + nd.bn_stats_floats(r));
+    if (!stats) w[off + i] = b;
     const float f = fisher[off + i] / nbr;
     mx = fmaxf(mx, f);
   }
@@ -298,9 +303,9 @@ extern "C" hipError_t load_flat_launch(const NetDesc *nd, float *w, const float 
   hipLaunchKernelGGL(load_flat_kernel, dim3(G), dim3(256), 0, st, *nd, w, flat, ld, flag);
   return hipGetLastError();
 }
-extern "C" hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat,
+extern "C" hipError_t ewc_setup_launch(const NetDesc *nd, float *w, const float *best, float *wstar, float *fisher, float *fhat,
                                        float *nbr, int stride, const uint8_t *flag, int G, hipStream_t st) {
-  hipLaunchKernelGGL(ewc_setup_kernel, dim3(G), dim3(256), 0, st, w, best, wstar, fisher, fhat, nbr, stride, flag);
+  hipLaunchKernelGGL(ewc_setup_kernel, dim3(G), dim3(256), 0, st, *nd, w, best, wstar, fisher, fhat, nbr, stride, flag);
   return hipGetLastError();
 }
 extern "C" hipError_t ewc_cost_launch(const float *w, const float *wstar, const float *fhat, int stride, float *out,

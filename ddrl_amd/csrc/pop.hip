@@ -46,7 +46,7 @@ hipError_t net_forward_wide_launch(const NetDesc *nd, const float *w, const floa
                                    const float *sgate, int S, const float *agate, int A, int gate_out, const GateMode *gm, hipStream_t st);
 hipError_t snapshot_launch(float *dst, const float *src, int stride, const uint8_t *flag, int G, hipStream_t st);
 hipError_t load_flat_launch(const NetDesc *nd, float *w, const float *flat, int ld, const uint8_t *flag, int G, hipStream_t st);
-hipError_t ewc_setup_launch(float *w, const float *best, float *wstar, float *fisher, float *fhat, float *nbr,
+hipError_t ewc_setup_launch(const NetDesc *nd, float *w, const float *best, float *wstar, float *fisher, float *fhat, float *nbr,
                             int stride, const uint8_t *flag, int G, hipStream_t st);
 hipError_t ewc_cost_launch(const float *w, const float *wstar, const float *fhat, int stride, float *out, int G,
                            hipStream_t st);
@@ -159,7 +159,6 @@ static int validate(const ddrl_ddpg_config *c) {
     if ((c->batch_norm_actor & 16) && !(c->batch_norm_actor & 4))
       return ddrl_fail(DDRL_EINVAL, "batch_norm_actor %d: first_except_action is a critic layout", c->batch_norm_actor);
     if (c->td3) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not served by the TD3 update");
-    if (c->ewc >= 0.) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 with devnn.ewc >= 0 is not supported");
     if (c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs mini_batch_size <= %d (the towers couple the rows of a minibatch)", DDRL_MB);
     if (c->force_more_update > 0 && c->bn_adapt) return ddrl_fail(DDRL_EINVAL, "bn_adapt with force_more_update > 0 is not supported");
     for (int i = 0; i < c->n_hidden_a; ++i) if (c->hidden_unit_a[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs layers of at most %d units", DDRL_MAXW);
@@ -1069,7 +1068,7 @@ static int ewc_setup_one(ddrl_pop *h, TrainNet &t, const uint8_t *mask) {
   if (!any) return DDRL_OK;
   int rc;
   if ((rc = upload_vec(h, h->d_flag, flag))) return rc;
-  HIPCHK(ewc_setup_launch(t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride(),
+  HIPCHK(ewc_setup_launch(&t.nd, t.st.w, t.st.best, t.st.wstar, t.st.fisher, t.st.fhat, t.st.fisher_nbr, t.nd.stride(),
                           h->d_flag, h->G, h->stream));
   DDRL_WAIT(h);
   return refresh_ewc_coef(h, t);
@@ -1116,9 +1115,11 @@ extern "C" int ddrl_pop_ewc_cost(ddrl_pop_t *h, int net, double *cost) {
   std::vector<float> c(h->G);
   HIPCHK(hipMemcpyAsync(c.data(), h->d_cost, h->G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   DDRL_WAIT(h);
+  int learnable = t.nd.np;                                  // the k of DODevMLP.hpp:679: parameters with lr_mult != 0 (not a tower's statistics)
+  for (int r = 0; r <= t.nd.L(); ++r) if (t.nd.bn(r)) learnable -= 2 * t.nd.bn_c(r) + 1;
   for (int g = 0; g < h->G; ++g) {
     if (!t.ewc.live[g]) continue;
-    double r = (double)c[g] * h->cfg.ewc / (double)t.nd.np;                // DODevMLP.hpp:679-683
+    double r = (double)c[g] * h->cfg.ewc / (double)learnable;             // DODevMLP.hpp:679-683
     cost[g] = h->cfg.ewc_decay < 0. ? r : r * t.ewc.decay_mult[g];
   }
   return DDRL_OK;

@@ -521,7 +521,11 @@ double ora_mlp_ewc_cost(const ora_mlp *n) {
     double x = n->best_prev[k] - n->w[k];
     cost += x * x * n->prev_fisher[k];
   }
-  double r = cost * n->ewc / ((double)n->np);
+  /* k of DODevMLP.hpp:679 counts the blobs with lr_mult != 0 only: a tower's statistics are not among them (their Fisher is 0:
+   * no gradient ever reaches them, so the sum above is unaffected) */
+  int k = 0;
+  for (int i = 0; i < n->np; ++i) k += !(n->frozen && n->frozen[i]);
+  double r = cost * n->ewc / ((double)k);
   if (n->ewc_decay < 0.) return r;
   return r * n->ewc_decay_mult;
 }
@@ -533,7 +537,8 @@ void ora_mlp_ewc_setup(ora_mlp *n) {
   n->best_score = -DBL_MAX;
   free(n->best_prev);
   n->best_prev = dupv(n->best_param, n->np);
-  memcpy(n->w, n->best_prev, sizeof(double) * n->np);  /* copyWeightsFrom(best_prev, true) */
+  for (int i = 0; i < n->np; ++i)                      /* copyWeightsFrom(best_prev, true): ignore_null_lr, the statistics stay */
+    if (!(n->frozen && n->frozen[i])) n->w[i] = n->best_prev[i];
   if (!n->fisher) { n->fisher = (double *)calloc(n->np, sizeof(double)); n->fisher_nbr = 0.; }
   for (int i = 0; i < n->np; ++i) n->fisher[i] = n->fisher[i] / n->fisher_nbr;
   double fmax = n->fisher[0];

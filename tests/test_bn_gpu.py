@@ -317,7 +317,84 @@ def test_ddpg_update_with_towers_and_gates(ora, bna, bnq, binary, adapt, inverti
     pop.close()
 
 
-@pytest.mark.parametrize("kw,msg", [(dict(mini_batch_size=128), "mini_batch_size"), (dict(ewc=0.5), "ewc"), (dict(batch_norm_actor=1), "without scaling"),
+@pytest.mark.parametrize("bna,bnq,for_critic", [(14, 11, 1), (7, 12, 0), (22, 19, 1)])
+def test_ewc_lifecycle_with_towers(ora, bna, bnq, for_critic):
+    """EWC (DODevMLP.hpp:604-758) on nets with towers: the EWC vectors hold the parameters with lr_mult != 0 only
+    (number_of_parameters(true), :641), so a tower's running statistics have no Fisher entry, are not restored by ewc_setup
+    (copyWeightsFrom(best, true), :616) and are not counted by ewc_cost's average (:679).  Teacher-forced like the other tower
+    tests: Fisher accumulation over a first task, the development switch, three updates with the penalty live, the cost."""
+    import oracle.oracle as o
+    G, B = 3, 64
+    pop, agents, frozen = make_bn_pair(ora, bna, bnq, G=G, seed=bna + bnq + 7, ewc=100.0, ewc_decay=0.9, ewc_fisher_beta=0.999,
+                                       ewc_for_critic=for_critic, ewc_best_method=0)
+    ewc_nets = (0, 1) if for_critic else (0,)
+    noise = critic_kills_action_gradient(bnq)
+    step = [0]
+
+    def one_update(check):
+        ws_prev = sync(pop, agents)
+        idx = np.random.RandomState(40 + step[0]).randint(0, 1000, (G, B)).astype(np.int32)
+        step[0] += 1
+        pop.update(idx)
+        for g, a in enumerate(agents):
+            a.update(idx[g])
+        if check:
+            check_update(pop, agents, frozen, ws_prev, actor_noise=noise)
+
+    for it in range(4):                                   # task 1: the running Fisher
+        one_update(False)
+    scores = np.array([1.0, 2.0, 3.0])
+    pop.update_best_param(scores)
+    for g, a in enumerate(agents):
+        sync(pop, agents)
+        a.ann.update_best_param(scores[g]); a.qnn.update_best_param(scores[g])
+    for it in range(2):
+        one_update(False)
+    for net in ewc_nets:
+        if net == 0 and noise:
+            continue
+        st = pop.ewc_state(net)
+        for g, a in enumerate(agents):
+            so = a.nets[net].ewc_state()
+            assert np.all(st["fisher"][g][frozen[net]] == 0) and np.all(so["fisher"][frozen[net]] == 0)
+            assert np.mean(np.abs(st["fisher"][g] - so["fisher"]) <= 1e-3 * np.max(so["fisher"])) >= 0.99, (net, g)
+            assert abs(st["fisher_nbr"][g] - so["fisher_nbr"]) <= 1e-5 * so["fisher_nbr"]
+    stats_before = [pop.weights(n)[:, frozen[n]] for n in (0, 1)]
+    w_before = [pop.weights(n) for n in (0, 1)]
+    pop.ewc_setup()                                       # the development switch
+    for a in agents:
+        a.ewc_setup()
+    for net in ewc_nets:
+        w = pop.weights(net)
+        st = pop.ewc_state(net)
+        assert np.array_equal(w[:, frozen[net]], stats_before[net])                    # the statistics stay ...
+        assert np.array_equal(w[:, ~frozen[net]], st["wstar"][:, ~frozen[net]])         # ... the parameters are the best ones again
+        assert not np.array_equal(w[:, ~frozen[net]], w_before[net][:, ~frozen[net]])
+        for g, a in enumerate(agents):
+            so = a.nets[net].ewc_state()
+            assert so["active"] == 1
+            assert np.all(st["fisher_hat"][g][frozen[net]] == 0)
+            if not (net == 0 and noise):
+                assert np.mean(np.abs(st["fisher_hat"][g] - so["fisher_hat"]) <= 1e-3 * np.max(so["fisher_hat"])) >= 0.99
+            # from here on the oracle carries the device's (fp32) EWC state
+            o.lib().ora_mlp_set_ewc(a.nets[net].h, st["fisher_hat"][g].ctypes.data, st["wstar"][g].ctypes.data)
+    if not for_critic:
+        assert np.array_equal(pop.weights(1), w_before[1])
+    for it in range(3):                                   # task 2: the penalty live, the Fisher average starts again
+        one_update(True)
+        pop.ewc_decay_update()
+        for a in agents:
+            o.lib().ora_mlp_ewc_decay_update(a.ann.h); o.lib().ora_mlp_ewc_decay_update(a.qnn.h)
+    sync(pop, agents)
+    for net in ewc_nets:
+        cost = pop.ewc_cost(net)
+        for g, a in enumerate(agents):
+            ref = a.nets[net].ewc_cost()
+            assert ref > 0 and abs(cost[g] - ref) <= 1e-4 * abs(ref), (net, g, cost[g], ref)
+    pop.close()
+
+
+@pytest.mark.parametrize("kw,msg", [(dict(mini_batch_size=128), "mini_batch_size"), (dict(batch_norm_actor=1), "without scaling"),
                                     (dict(batch_norm_actor=3), "without bn"), (dict(batch_norm_actor=18), "critic layout"),
                                     (dict(hidden_unit_a=(200,)), "128")])
 def test_refusals(kw, msg):
