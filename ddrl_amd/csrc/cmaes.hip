@@ -985,50 +985,71 @@ cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, i
 }
 
 // The WHOLE decomposition in one launch: the nb2 / 2 workgroups (at most 64, one per CU: all resident at once) loop over the sweeps'
-// rounds themselves and meet at a barrier in memory after each -- a round's kernel boundary (drain, cache write-back, dispatch:
-// ~7 us against ~12 us of work) and the host's look at the rotation count after every sweep go.  ctl[0] counts arrivals (never
-// reset inside a launch: round e waits for (e + 1) * workgroups), ctl[1] is raised by a workgroup that has waited longer than
-// JACOBI_BARRIER_TICKS of the 100 MHz clock (a workgroup that is not resident: another process holds CUs) -- every workgroup then
-// leaves at its next look, and the host carries on from that state with the launch-per-round path.  ctl[2] = sweeps done,
-// ctl[8 + 2 s], ctl[9 + 2 s]: sweep s's rotation count and worst ratio.  A workgroup's rows reach the others through agent-scope
-// stores and loads (no write-back / invalidation of a whole L2 at every barrier, which costs what the kernel boundary did): every
-// wave waits for its stores' acknowledgements before the workgroup's arrival is counted.
+// rounds themselves -- a round's kernel boundary (drain, cache write-back, dispatch: ~7 us against ~12 us of work) and the host's
+// look at the rotation count after every sweep go.  Inside a sweep there is no barrier at all: a block's rows are touched by
+// its owner of the round only, so a workgroup entering round e + 1 needs nothing but its two blocks' rows as their owners of
+// round e left them.  Every block has a counter of the rounds it has been through (`done`, behind the sweeps' counters in
+// ctl): a workgroup publishes e + 1 for its two blocks once every wave's stores have been acknowledged, and waits for its next
+// two blocks to show e + 1 before it fetches them -- the tournament's data flow, nothing more; fast pairs run ahead of slow
+// ones.  At the end of a sweep the workgroups meet once (ctl[0] counts arrivals, never reset inside a launch) so that all
+// read the same rotation count.  A workgroup's rows reach the others through agent-scope stores and loads (`sc1`: no
+// write-back / invalidation of a whole L2, which costs what the kernel boundary did).  ctl[1] is raised by a workgroup that has
+// waited longer than JACOBI_BARRIER_TICKS of the 100 MHz clock (a workgroup that is not resident: another process holds
+// CUs) -- every workgroup then leaves at its next look (no wave spins for ever), and the host carries on from that state with
+// the launch-per-round path (whole rounds of disjoint row pairs: any such state is a valid iterate).  ctl[2] = sweeps done,
+// ctl[8 + 2 s], ctl[9 + 2 s]: sweep s's rotation count and worst ratio.
 #define JACOBI_MAX_SWEEPS 60
-#define JACOBI_CTL_INTS (8 + 2 * JACOBI_MAX_SWEEPS)
+#define JACOBI_MAX_BLOCKS (2 * JF / JB)           // blocks of the largest N the one-trip round serves (1024 / 8)
+#define JACOBI_CTL_INTS (8 + 2 * JACOBI_MAX_SWEEPS + JACOBI_MAX_BLOCKS)
 #define JACOBI_BARRIER_TICKS 200000000ll          // 2 s
 #define JACOBI_PERSIST_JFG 5                      // widest instantiation of the one-launch kernel (N <= 640): beyond, its loop's registers spill
+// thread 0 of a workgroup: wait until *p >= want (agent scope); false: gave up (own time limit, or another workgroup's)
+__device__ __forceinline__ bool jacobi_wait_for(int *p, int want, int *abort_flag) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    if (wall_clock64() - t0 > JACOBI_BARRIER_TICKS) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
 template <int JFG>
 __global__ void __launch_bounds__(JF)
 cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl) {
   extern __shared__ __align__(16) double jsm[];
   __shared__ int go;
-  const int tid = threadIdx.x, nwg = gridDim.x;
-  int epoch = 0;
+  const int tid = threadIdx.x, b = blockIdx.x, nwg = gridDim.x, m = nb2 - 1;
+  int *done = ctl + 8 + 2 * JACOBI_MAX_SWEEPS;      // [nb2]: rounds each block has been through
+  int e = 0;                                        // rounds this workgroup has finished
   for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
     int *rotated = ctl + 8 + 2 * sweep;
     for (int step = 0; step < nb2 - 1; ++step) {
+      const int P = b == 0 ? m : (step + b) % m, Q = b == 0 ? step : (step - b + m) % m;      // jacobi_fast_round's pairing
+      if (e > 0) {
+        if (tid == 0) go = jacobi_wait_for(done + P, e, ctl + 1) && jacobi_wait_for(done + Q, e, ctl + 1);
+        __syncthreads();
+        if (!go) return;                            // uniform
+      }
       jacobi_fast_round<true, JFG>(G, W, N, ldt, nb2, step, rotated, jsm);
       __builtin_amdgcn_s_waitcnt(0);                // this wave's stores have been acknowledged
-      __syncthreads();
+      __syncthreads();                              // (also: `go` has been read by every thread before it is written again)
+      ++e;
       if (tid == 0) {
-        ++epoch;
-        __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = wall_clock64();
-        int ok = 1;
-        while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nwg) {
-          if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
-          if (wall_clock64() - t0 > JACOBI_BARRIER_TICKS) { __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
-          __builtin_amdgcn_s_sleep(2);
-        }
-        go = ok;
+        __hip_atomic_store(done + P, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done + Q, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __syncthreads();
-      if (!go) return;                              // uniform
     }
-    // every workgroup reads the same count: all arrivals of the sweep's last round are behind it
+    // the sweep's end: every workgroup reads the same count once all have arrived (their counts were added before)
+    if (tid == 0) {
+      __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      go = jacobi_wait_for(ctl, (sweep + 1) * nwg, ctl + 1);
+    }
+    __syncthreads();
+    if (!go) return;
     const int rot = __hip_atomic_load(rotated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0 && tid == 0) ctl[2] = sweep + 1;
+    if (b == 0 && tid == 0) ctl[2] = sweep + 1;
     if (rot == 0) return;
+    __syncthreads();                                // `go` is written again at the next round's wait
   }
 }
 extern "C" size_t cmaes_jacobi_fast_lds(int ldt) {
