@@ -53,7 +53,7 @@ __device__ __forceinline__ bool wide_skip(const DdpgParams &P, int agent, int ch
   return len < 250 || len < P.B || chunk * DDRL_MB >= P.B;
 }
 
-struct WideOp { int net, target, l, mode, policy; };      // net: 0 actor, 1 critic, 2 second critic (TD3)
+struct WideOp { int net, target, l, mode, policy, agent0, ng; };      // net: 0 actor, 1 critic, 2 second critic (TD3); the launch covers agents [agent0, agent0 + ng)
 
 // where layer l of a net reads its input / writes its output inside the scratch block
 __device__ __forceinline__ void wide_io(const DdpgParams &P, const WideMap &W, int net, int l, const NetDesc &nd,
@@ -77,7 +77,8 @@ wide_fwd_kernel(const DdpgParams P, const WideOp op) {
   const NetDesc &nd = op.net ? P.q : P.a;
   const int l = op.l, kp = nd.kp(l), N = nd.d(l + 1);
   int nb, chunk, agent;
-  if (!xcd_decode((nd.ld(l + 1) + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, nb, chunk, agent)) return;
+  if (!xcd_decode((nd.ld(l + 1) + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, op.ng, nb, chunk, agent)) return;
+  agent += op.agent0;
   if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
@@ -147,7 +148,8 @@ wide_dx_kernel(const DdpgParams P, const WideOp op) {
   const NetDesc &nd = op.net ? P.q : P.a;
   const int l = op.l, kp = nd.kp(l), K = nd.d(l), N = nd.d(l + 1);
   int kb, chunk, agent;
-  if (!xcd_decode((kp + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, P.G, kb, chunk, agent)) return;
+  if (!xcd_decode((kp + 63) / 64, (P.B + DDRL_MB - 1) / DDRL_MB, op.ng, kb, chunk, agent)) return;
+  agent += op.agent0;
   if (wide_skip(P, agent, chunk, op.policy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const NetState &st = op.net == 2 ? P.sq2 : op.net ? P.sq : P.sa;
@@ -222,7 +224,7 @@ template <bool EWC>
 __global__ void __launch_bounds__(256)
 wide_dw_kernel(const DdpgParams P, const WideOp op) {
   __shared__ __align__(16) float sY[DDRL_MB * 68], sX[DDRL_MB * 68];
-  const int nb = blockIdx.x, agent = blockIdx.z;
+  const int nb = blockIdx.x, agent = blockIdx.z + op.agent0;
   if (wide_skip(P, agent, 0, op.policy)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
   const NetDesc &nd = op.net ? P.q : P.a;
@@ -280,8 +282,8 @@ wide_dw_kernel(const DdpgParams P, const WideOp op) {
 
 // the element-wise steps between the layer launches, one workgroup per (chunk, agent)
 __global__ void __launch_bounds__(DDRL_NTHREADS)
-wide_step_kernel(const DdpgParams P, int step, int policy) {
-  const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x;
+wide_step_kernel(const DdpgParams P, int step, int policy, int agent0) {
+  const int chunk = blockIdx.x, agent = blockIdx.y + agent0, tid = threadIdx.x;
   if (wide_skip(P, agent, chunk, policy)) return;
   const WideMap W = wide_map(P, agent, chunk);
   const LdsMap &M = W.M;
@@ -414,27 +416,26 @@ extern "C" size_t ddpg_wide_block_floats(const DdpgParams *P) { return wide_bloc
 
 // td3 == 0: DeepQNAg's update.  td3 != 0: TD3Ag's (TD3Ag.hpp:284-380) -- smoothed target action, two target
 // critics, both critics' learn_batch, and (any_actor: some agent is on a policy step) the actor phase
-// launched for those agents only.
-static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipStream_t st) {
-  const DdpgParams &P = *Pp;
-  const int C = (P.B + DDRL_MB - 1) / DDRL_MB, G = P.G;
+// launched for those agents only.  The launches cover agents [a0, a0 + G) and go to stream st.
+static hipError_t wide_launch_range(const DdpgParams &P, int td3, int any_actor, int a0, int G, hipStream_t st) {
+  const int C = (P.B + DDRL_MB - 1) / DDRL_MB;
   int policy = 0;                                           // set for the launches of TD3's actor phase
-  auto step = [&](int s) { hipLaunchKernelGGL(wide_step_kernel, dim3(C, G), dim3(DDRL_NTHREADS), 0, st, P, s, policy); };
+  auto step = [&](int s) { hipLaunchKernelGGL(wide_step_kernel, dim3(C, G), dim3(DDRL_NTHREADS), 0, st, P, s, policy, a0); };
   auto fwd = [&](int net, int target) {
     const NetDesc &nd = net ? P.q : P.a;
     for (int l = 0; l < nd.L_; ++l) {
-      const WideOp op = {net, target, l, 0, policy};
+      const WideOp op = {net, target, l, 0, policy, a0, G};
       hipLaunchKernelGGL(wide_fwd_kernel, dim3(xcd_grid((nd.ld_[l + 1] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
     }
   };
   auto dx = [&](int net, int l, int mode) {
     const NetDesc &nd = net ? P.q : P.a;
-    const WideOp op = {net, 0, l, mode, policy};
+    const WideOp op = {net, 0, l, mode, policy, a0, G};
     hipLaunchKernelGGL(wide_dx_kernel, dim3(xcd_grid((nd.kp_[l] + 63) / 64, C, G)), dim3(256), 0, st, P, op);
   };
   auto dw = [&](int net, int l) {          // all chunks of the minibatch in one workgroup: grid.y = 1
     const NetDesc &nd = net ? P.q : P.a;
-    const WideOp op = {net, 0, l, 0, policy};
+    const WideOp op = {net, 0, l, 0, policy, a0, G};
     const dim3 grid((nd.d_[l + 1] + 63) / 64, 1, G);
     const bool ewc = (net == 2 ? P.sq2 : net ? P.sq : P.sa).fisher != nullptr;
     if (ewc) hipLaunchKernelGGL((wide_dw_kernel<true>), grid, dim3(256), 0, st, P, op);
@@ -481,6 +482,50 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
   for (int l = P.a.L_ - 1; l >= 0; --l) { if (l > 0) dx(0, l, 0); dw(0, l); }
   WIDE_CHECK();
   return finish(0);
+}
+
+// The update is a chain of ~45 launches that alternate between matrix-core-bound kernels (forward, input gradients) and
+// HBM-bound ones (dW + optimiser: 52 B of state per parameter).  Agents are independent, so a large population is cut in two
+// parts (WIDE_PARTS_DEFAULT) whose chains run on streams of their own: while one half streams its optimiser state the other half's products run, instead
+// of the whole chip waiting on one resource at a time.  The second stream and the two events of the fork / join are made
+// once per device and kept; results are the same launches over the same agents (bit-identical).
+#define WIDE_SPLIT_MIN_AGENTS 128
+#define WIDE_MAX_PARTS 4
+#define WIDE_PARTS_DEFAULT 2
+static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipStream_t st) {
+  const DdpgParams &P = *Pp;
+  static const int parts_env = getenv("DDRL_WIDE_PARTS") ? atoi(getenv("DDRL_WIDE_PARTS")) : 0;      // (measurement switch; 1: no split)
+  const int parts = parts_env >= 1 && parts_env <= WIDE_MAX_PARTS ? parts_env : WIDE_PARTS_DEFAULT;
+  if (P.G < WIDE_SPLIT_MIN_AGENTS || parts == 1) return wide_launch_range(P, td3, any_actor, 0, P.G, st);
+  struct Aux { hipStream_t s[WIDE_MAX_PARTS - 1] = {}; hipEvent_t fork = nullptr, join[WIDE_MAX_PARTS - 1] = {}; bool made = false; };
+  static Aux aux[64];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return wide_launch_range(P, td3, any_actor, 0, P.G, st);
+  Aux &a = aux[dev];
+  if (!a.made) {
+    if ((e = hipEventCreateWithFlags(&a.fork, hipEventDisableTiming)) != hipSuccess) return e;
+    for (int k = 0; k < WIDE_MAX_PARTS - 1; ++k) {
+      if ((e = hipStreamCreateWithFlags(&a.s[k], hipStreamNonBlocking)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&a.join[k], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    a.made = true;
+  }
+  if ((e = hipEventRecord(a.fork, st)) != hipSuccess) return e;
+  for (int k = 0; k < parts - 1; ++k)
+    if ((e = hipStreamWaitEvent(a.s[k], a.fork, 0)) != hipSuccess) return e;
+  hipError_t first = hipSuccess;
+  for (int k = 0; k < parts; ++k) {
+    const int a0 = (int)((long long)P.G * k / parts), a1 = (int)((long long)P.G * (k + 1) / parts);
+    const hipError_t ek = wide_launch_range(P, td3, any_actor, a0, a1 - a0, k == 0 ? st : a.s[k - 1]);
+    if (first == hipSuccess) first = ek;
+  }
+  for (int k = 0; k < parts - 1; ++k) {               // joined whatever the launches said: st never runs ahead of a part
+    if ((e = hipEventRecord(a.join[k], a.s[k])) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(st, a.join[k], 0)) != hipSuccess) return e;
+  }
+  return first;
 }
 
 extern "C" hipError_t ddpg_update_wide_launch(const DdpgParams *P, hipStream_t st) { return wide_launch(P, 0, 0, st); }

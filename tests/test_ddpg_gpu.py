@@ -613,3 +613,48 @@ def test_eight_waves_per_agent_bit_identical(ora, kw):
         assert np.array_equal(la[k], lb[k]), k
     assert list(a.adam(0)[2]) == [4 + n, 4 + n, 3, 4 + n, 4 + n]
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("td3", [False, True])
+def test_wide_update_over_two_streams_is_the_same_update(td3):
+    """Layers wider than 128 (the layer-by-layer kernels): from 128 agents on, the launch chain is cut into two halves of the
+    population on two streams (kernels_ddpg_wide.hip, wide_launch).  Agents are independent, so an agent's update must not
+    depend on how many agents the handle holds: agents 0, 64 (first half) and 129 (second half) of a 130-agent population
+    against a 3-agent population holding the same three agents -- weights, targets and Adam moments bit for bit, three
+    updates, DDPG and TD3 (delayed policy step included)."""
+    import ddrl_amd
+    from ddpg_common import synth_transitions
+    S, A, B, Gbig, pick = 18, 6, 64, 130, (0, 64, 129)
+    kw = dict(nb_sensors=S, nb_motors=A, hidden_unit_a=(160, 130), hidden_unit_q=(140, 129), replay_memory=600, mini_batch_size=B,
+              inverting_grad=1, ewc=100.0, ewc_for_critic=1)
+    cls = ddrl_amd.DdpgPopulation
+    if td3:
+        kw.update(td3=1, inverting_grad=0, policy_noise=0.2, noise_clip=0.5, policy_freq=2)
+        cls = ddrl_amd.Td3Population
+    big = cls(ddrl_amd.DdpgConfig(n_agents=Gbig, **kw), init_seed=11)
+    small = cls(ddrl_amd.DdpgConfig(n_agents=len(pick), **kw), init_seed=12)
+    nets = range(6 if td3 else 4)
+    for n in nets:
+        small.set_weights(n, big.weights(n)[list(pick)])
+    rows = {g: synth_transitions(np.random.RandomState(100 + g), 500, S, A) for g in pick}
+    filler = synth_transitions(np.random.RandomState(7), 500, S, A)
+    for g in range(Gbig):
+        big.replay_load(g, rows.get(g, filler))
+    for k, g in enumerate(pick):
+        small.replay_load(k, rows[g])
+    for upd in range(3):
+        idx = np.random.RandomState(50 + upd).randint(0, 500, (Gbig, B)).astype(np.int32)
+        if td3:
+            noise = np.random.RandomState(60 + upd).normal(0, 0.2, (Gbig, B, A)).astype(np.float32)
+            big.update(idx, noise=noise, actor_step=upd % 2)
+            small.update(np.ascontiguousarray(idx[list(pick)]), noise=np.ascontiguousarray(noise[list(pick)]), actor_step=upd % 2)
+        else:
+            big.update(idx)
+            small.update(np.ascontiguousarray(idx[list(pick)]))
+    for n in nets:
+        assert np.array_equal(big.weights(n)[list(pick)], small.weights(n)), n
+    for n in ((0, 1, 4) if td3 else (0, 1)):
+        mb, vb, ib = big.adam(n)
+        ms, vs, is_ = small.adam(n)
+        assert np.array_equal(mb[list(pick)], ms) and np.array_equal(vb[list(pick)], vs) and np.array_equal(ib[list(pick)], is_)
+    big.close(); small.close()
