@@ -1653,6 +1653,7 @@ extern "C" int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int m
 //   "device_rng" (0/1): draw z on the device (Philox) instead of evaluating c-cmaes' sequential
 //   generator on the host;  "device_eigen" (0/1): eigendecomposition by one-sided Jacobi on the GPU (device_eigen above);
 //   "eigen_block" (1/0): its rounds over blocks of rows (default) or over single rows.
+//   "eigen_persist" (1/0): all sweeps of a decomposition in one launch (default, N <= 640) or one launch per round.
 extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value) {
   if (!h || !key) return ddrl_fail(DDRL_EINVAL, "NULL argument");
   if (std::string(key) == "device_rng") { h->device_rng = value != 0; return DDRL_OK; }
