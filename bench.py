@@ -217,6 +217,9 @@ def build_population(G, rank, first_agent, S, A, B, ha, hq, ewc, replay, local_r
     return pop
 
 
+SETUP_UPDATES = 64
+
+
 def timed_sweep(pop, G, steps, warmup, upl, ewc, barrier):
     """W untimed + K timed population updates; returns (seconds, kernel_ms, launches)"""
     def run_updates(k):              # k updates of every agent ("steps"), upl per launch
@@ -226,8 +229,11 @@ def timed_sweep(pop, G, steps, warmup, upl, ewc, barrier):
         if rem:
             pop.update_n(rem) if rem > 1 else pop.update()
 
-    # bring EWC to its steady state: Fisher accumulated, snapshot taken, penalty live
-    run_updates(upl)
+    # set-up, before the W warm-up steps the caller asked for: SETUP_UPDATES updates bring EWC to the state a sweep runs in
+    # (Fisher average accumulated -- its horizon is 1 / (1 - 0.999) updates --, snapshot taken, penalty live).  They are also what
+    # takes the GPU out of its idle state after the host-side replay loading: with one launch here, a short run (K = 20) measured
+    # 0.377 ms per update against 0.364 ms with these (same box; 0.350 ms at K = 200): reported as config.setup_updates.
+    run_updates(max(upl, SETUP_UPDATES // upl * upl))
     if ewc:
         pop.update_best_param(np.ones(G))
         pop.ewc_setup()
@@ -591,7 +597,8 @@ def main():
                                "%d agents per GPU, replay %d/agent, device mt19937 replay sampling; %d consecutive updates per launch "
                                "(the fupd loop, force_more_update=%d)"
                                % ("+EWC" if ewc else "", args.size, "x".join(map(str, ha)), "x".join(map(str, hq)), G, args.replay, upl, upl - 1),
-                   "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective"},
+                   "agents_per_gpu": G, "agents_total": world * G, "parallelism": "agents sharded, no collective",
+                   "setup_updates": max(upl, SETUP_UPDATES // upl * upl)},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ("ddpg_update_pair_kernel" if (PAIR_MODE == 2 or (upl >= 4 and PAIR_MODE and args.size == "mid" and G > 512)) else
