@@ -338,6 +338,8 @@ struct ddrl_cmaes {
   int sweep_graph_block = 0;             // which of the two the captured sweep holds
   int eigen_persist = 1;                 // ... and all sweeps in one launch with barriers in memory (cmaes_jacobi_sweeps_fast) where the one-trip round serves
   int eigen_persist_timeouts = 0;        // launches that gave up at a barrier (and were finished round by round)
+  int eigen_persist_wait_ms = 2000;      // a workgroup's patience at a hand-over
+  int eigen_persist_drop = 0;            // (tests) workgroups left out of the launch
   int eigen_sweeps = 0;                  // sweeps the last device eigendecomposition took
   hipGraphExec_t sweep_graph = nullptr;  // one Jacobi sweep (N - 1 rounds) as a captured graph
   bool sweep_graph_failed = false;
@@ -994,31 +996,30 @@ cmaes_jacobi_block_fast(double *__restrict__ G, double *__restrict__ W, int N, i
 // ones.  At the end of a sweep the workgroups meet once (ctl[0] counts arrivals, never reset inside a launch) so that all
 // read the same rotation count.  A workgroup's rows reach the others through agent-scope stores and loads (`sc1`: no
 // write-back / invalidation of a whole L2, which costs what the kernel boundary did).  ctl[1] is raised by a workgroup that has
-// waited longer than JACOBI_BARRIER_TICKS of the 100 MHz clock (a workgroup that is not resident: another process holds
+// waited longer than its patience (2 s of the 100 MHz clock; option "eigen_persist_wait_ms") (a workgroup that is not resident: another process holds
 // CUs) -- every workgroup then leaves at its next look (no wave spins for ever), and the host carries on from that state with
 // the launch-per-round path (whole rounds of disjoint row pairs: any such state is a valid iterate).  ctl[2] = sweeps done,
 // ctl[8 + 2 s], ctl[9 + 2 s]: sweep s's rotation count and worst ratio.
 #define JACOBI_MAX_SWEEPS 60
 #define JACOBI_MAX_BLOCKS (2 * JF / JB)           // blocks of the largest N the one-trip round serves (1024 / 8)
 #define JACOBI_CTL_INTS (8 + 2 * JACOBI_MAX_SWEEPS + JACOBI_MAX_BLOCKS)
-#define JACOBI_BARRIER_TICKS 200000000ll          // 2 s
 #define JACOBI_PERSIST_JFG 5                      // widest instantiation of the one-launch kernel (N <= 640): beyond, its loop's registers spill
 // thread 0 of a workgroup: wait until *p >= want (agent scope); false: gave up (own time limit, or another workgroup's)
-__device__ __forceinline__ bool jacobi_wait_for(int *p, int want, int *abort_flag) {
+__device__ __forceinline__ bool jacobi_wait_for(int *p, int want, int *abort_flag, long long ticks) {
   const long long t0 = wall_clock64();
   while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    if (wall_clock64() - t0 > JACOBI_BARRIER_TICKS) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    if (wall_clock64() - t0 > ticks) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
     __builtin_amdgcn_s_sleep(1);
   }
   return true;
 }
 template <int JFG>
 __global__ void __launch_bounds__(JF)
-cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl) {
+cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl, long long ticks) {
   extern __shared__ __align__(16) double jsm[];
   __shared__ int go;
-  const int tid = threadIdx.x, b = blockIdx.x, nwg = gridDim.x, m = nb2 - 1;
+  const int tid = threadIdx.x, b = blockIdx.x, nwg = nb2 / 2, m = nb2 - 1;      // (nwg: the grid the rounds need, whatever was launched)
   int *done = ctl + 8 + 2 * JACOBI_MAX_SWEEPS;      // [nb2]: rounds each block has been through
   int e = 0;                                        // rounds this workgroup has finished
   for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
@@ -1026,7 +1027,7 @@ cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl
     for (int step = 0; step < nb2 - 1; ++step) {
       const int P = b == 0 ? m : (step + b) % m, Q = b == 0 ? step : (step - b + m) % m;      // jacobi_fast_round's pairing
       if (e > 0) {
-        if (tid == 0) go = jacobi_wait_for(done + P, e, ctl + 1) && jacobi_wait_for(done + Q, e, ctl + 1);
+        if (tid == 0) go = jacobi_wait_for(done + P, e, ctl + 1, ticks) && jacobi_wait_for(done + Q, e, ctl + 1, ticks);
         __syncthreads();
         if (!go) return;                            // uniform
       }
@@ -1042,7 +1043,7 @@ cmaes_jacobi_sweeps_fast(double *G, double *W, int N, int ldt, int nb2, int *ctl
     // the sweep's end: every workgroup reads the same count once all have arrived (their counts were added before)
     if (tid == 0) {
       __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      go = jacobi_wait_for(ctl, (sweep + 1) * nwg, ctl + 1);
+      go = jacobi_wait_for(ctl, (sweep + 1) * nwg, ctl + 1, ticks);
     }
     __syncthreads();
     if (!go) return;
@@ -1081,7 +1082,7 @@ static int device_eigen(ddrl_cmaes *h) {
   // the one-trip kernels are compiled per number of 16-column groups a wave holds (their registers): 1 .. JFG_MAX
   const int jfg = ((N + 15) / 16 + JF / 64 - 1) / (JF / 64);
   typedef void (*round_fn)(double *, double *, int, int, int, int, int *);
-  typedef void (*sweeps_fn)(double *, double *, int, int, int, int *);
+  typedef void (*sweeps_fn)(double *, double *, int, int, int, int *, long long);
   static const round_fn round_k[JFG_MAX] = {cmaes_jacobi_block_fast<1>, cmaes_jacobi_block_fast<2>, cmaes_jacobi_block_fast<3>, cmaes_jacobi_block_fast<4>,
                                             cmaes_jacobi_block_fast<5>, cmaes_jacobi_block_fast<6>, cmaes_jacobi_block_fast<7>, cmaes_jacobi_block_fast<8>};
   static const sweeps_fn sweeps_k[JACOBI_PERSIST_JFG] = {cmaes_jacobi_sweeps_fast<1>, cmaes_jacobi_sweeps_fast<2>, cmaes_jacobi_sweeps_fast<3>,
@@ -1137,13 +1138,16 @@ static int device_eigen(ddrl_cmaes *h) {
       HIPCHK(ddrl_set_lds(sweeps_k[jfg - 1], cmaes_jacobi_fast_lds(ldt), conf2[jfg - 1]));
       std::vector<int> ctl(JACOBI_CTL_INTS);
       HIPCHK(hipMemsetAsync(h->d_info, 0, ctl.size() * sizeof(int), h->stream));
-      hipLaunchKernelGGL(sweeps_k[jfg - 1], dim3(n2 / 2), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, h->d_info);
+      // (eigen_persist_drop: a test's way to a workgroup that never arrives -- the grid is launched short)
+      const int grid = std::max(1, n2 / 2 - h->eigen_persist_drop);
+      hipLaunchKernelGGL(sweeps_k[jfg - 1], dim3(grid), dim3(JF), cmaes_jacobi_fast_lds(ldt), h->stream, h->d_A, h->d_W, N, ldt, n2, h->d_info,
+                         (long long)h->eigen_persist_wait_ms * 100000ll);
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(ctl.data(), h->d_info, ctl.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       if (trace) for (int s2 = 0; s2 < ctl[2]; ++s2) say(s2, ctl[8 + 2 * s2], ctl[9 + 2 * s2]);
       if (ctl[1]) {                                 // a workgroup was not resident within the barrier's bound: the matrices are a valid
-        h->eigen_persist_timeouts++;                // intermediate state (whole rounds only), the rounds below carry on from it
+        if (++h->eigen_persist_timeouts >= 2) h->eigen_persist = 0;     // intermediate state (whole rounds only), the rounds below carry on from it; twice: this GPU is shared, no third wait
         if (trace) fprintf(stderr, "[cmaes] the one-launch decomposition gave up at a barrier after %d sweeps: launch per round from here\n", ctl[2]);
       } else if (ctl[2] > 0 && ctl[8 + 2 * (ctl[2] - 1)] == 0) {
         sweeps = ctl[2] - 1;
@@ -1553,7 +1557,7 @@ extern "C" int ddrl_cmaes_get(ddrl_cmaes_t *h, const char *key, double *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return DDRL_OK;
   }
-  if (k == "eigen_sweeps") *out = h->eigen_sweeps; else if (k == "eigen_persist_timeouts") *out = h->eigen_persist_timeouts; else if (k == "gen") *out = h->gen; else if (k == "lambda") *out = h->lambda; else if (k == "mu") *out = h->mu;
+  if (k == "eigen_sweeps") *out = h->eigen_sweeps; else if (k == "eigen_persist_timeouts") *out = h->eigen_persist_timeouts; else if (k == "eigen_persist") *out = h->eigen_persist; else if (k == "gen") *out = h->gen; else if (k == "lambda") *out = h->lambda; else if (k == "mu") *out = h->mu;
   else if (k == "N" || k == "dim") *out = h->N; else if (k == "mueff") *out = h->mueff; else if (k == "cs") *out = h->cs;
   else if (k == "damps") *out = h->damps; else if (k == "ccumcov") *out = h->ccumcov; else if (k == "ccov") *out = h->ccov;
   else if (k == "mucov") *out = h->mucov; else if (k == "chiN") *out = h->chiN; else if (k == "modulo") *out = h->modulo;
@@ -1669,6 +1673,8 @@ extern "C" int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value
     h->eig_warm = 0;
     return DDRL_OK;
   }
+  if (std::string(key) == "eigen_persist_wait_ms") { h->eigen_persist_wait_ms = std::max(1, std::min(value, 10000)); return DDRL_OK; }
+  if (std::string(key) == "eigen_persist_drop") { h->eigen_persist_drop = std::max(0, value); return DDRL_OK; }     // tests only
   if (std::string(key) == "eigen_persist") { h->eigen_persist = value != 0; return DDRL_OK; }  // 1 (default): one launch per decomposition; 0: one per round
   if (std::string(key) == "eigen_block") { h->eigen_block = value != 0; return DDRL_OK; }      // 1 (default): blocked rounds; 0: one row pair per workgroup
   return ddrl_fail(DDRL_EINVAL, "unknown option '%s'", key);

@@ -460,8 +460,9 @@ int ddrl_cmaes_test_for_termination(ddrl_cmaes_t *h, char *msg, int msg_len);
  * the host otherwise) by this library's one-sided Jacobi kernels in fp64 on the GPU; "eigen_block" (1/0, default 1): their rounds
  * over blocks of 8 rows (78 per sweep at N = 631) instead of single rows (630); "eigen_persist" (1/0, default 1; N <= 640): the
  * whole decomposition in one launch whose workgroups hand their rows to each other in memory (a bounded wait: if a workgroup is
- * not resident within 2 s the launch gives up, the decomposition is finished with one launch per round, and the handle's
- * "eigen_persist_timeouts" counter -- ddrl_cmaes_get -- says so) instead of one launch per round.  Same algorithm, different
+ * not resident within 2 s -- "eigen_persist_wait_ms" -- the launch gives up, the decomposition is finished with one launch per
+ * round, and the handle's "eigen_persist_timeouts" counter -- ddrl_cmaes_get -- says so; after two such launches the handle
+ * stays with one launch per round) instead of one launch per round.  Same algorithm, different
  * stream / eigenbasis: no counterpart in the reference. */
 int ddrl_cmaes_set_option(ddrl_cmaes_t *h, const char *key, int value);
 

@@ -256,6 +256,30 @@ def test_device_eigen_against_the_host_routines(N, block):
         assert np.max(np.abs(B.T @ B - np.eye(N))) < 1e-6
 
 
+def test_one_launch_decomposition_gives_up_and_is_finished_round_by_round():
+    """The one-launch eigendecomposition's workgroups wait for each other in memory, with a time limit: a workgroup that
+    never arrives (here: left out of the launch by a test option; in the field: a GPU whose CUs another process holds) makes
+    the others give up, and the host finishes the decomposition with one launch per round from the state they left.  The
+    result is the same eigensystem; after two such launches the handle stops trying."""
+    from ddrl_amd.cmaes import Cmaes
+    N, lam = 151, 302
+    es = Cmaes(np.linspace(-0.5, 0.5, N), np.linspace(0.2, 0.6, N), 7, lam)
+    es.set_option("device_eigen", 1)
+    es.set_option("eigen_persist_drop", 1)
+    es.set_option("eigen_persist_wait_ms", 20)
+    for g in range(4):
+        X = es.sample()
+        if g >= 1:                                  # the eigensystem the sample was drawn from, against an independent solver
+            Cm, B, D = es.vec("C"), es.vec("B"), es.vec("D")
+            ev = np.linalg.eigvalsh(Cm)
+            assert np.max(np.abs(np.sort(D * D) - ev)) <= 1e-10 * ev.max(), g
+            assert nerr(B @ np.diag(D * D) @ B.T, Cm) < 1e-6
+            assert np.max(np.abs(B.T @ B - np.eye(N))) < 1e-6
+        es.update(((X - 0.1) ** 2).sum(1) + np.arange(lam) * 1e-9)
+    assert int(es.get("eigen_persist_timeouts")) == 2 and int(es.get("eigen_persist")) == 0
+    es.close()
+
+
 def test_update_dev_equals_update_and_device_generation():
     """ddrl_cmaes_update_dev on a device buffer (what the RCCL fitness all-gather produces, ddrl_amd/shard.py) == ddrl_cmaes_update
     on the same values from the host, bit for bit; and ShardedCmaes.generation_dev (torch view of the library's X, fitness
