@@ -160,7 +160,6 @@ static int validate(const ddrl_ddpg_config *c) {
       return ddrl_fail(DDRL_EINVAL, "batch_norm_actor %d: first_except_action is a critic layout", c->batch_norm_actor);
     if (c->td3) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not served by the TD3 update");
     if (c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs mini_batch_size <= %d (the towers couple the rows of a minibatch)", DDRL_MB);
-    if (c->force_more_update > 0 && c->bn_adapt) return ddrl_fail(DDRL_EINVAL, "bn_adapt with force_more_update > 0 is not supported");
     for (int i = 0; i < c->n_hidden_a; ++i) if (c->hidden_unit_a[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs layers of at most %d units", DDRL_MAXW);
     for (int i = 0; i < c->n_hidden_q; ++i) if (c->hidden_unit_q[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs layers of at most %d units", DDRL_MAXW);
     if (c->nb_sensors + c->nb_motors > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs nb_sensors + nb_motors <= %d", DDRL_MAXW);

@@ -317,6 +317,38 @@ def test_ddpg_update_with_towers_and_gates(ora, bna, bnq, binary, adapt, inverti
     pop.close()
 
 
+@pytest.mark.parametrize("adapt", [True, False])
+def test_fupd_loop_with_towers(ora, adapt):
+    """force_more_update > 0 on tower nets (DeepQNAg.hpp:341, 415-420, 469-472): the passes of one end_episode run back to back,
+    and ann_testing -- whose actions the critic scores under bn_adapt -- is the actor as of the END OF THE PREVIOUS end_episode in
+    every one of them; it follows only after the loop.  Three passes per call, two calls, free-running inside a call (fp32 against
+    fp64 through normalisations: 3e-4 norm-wise), teacher-forced between the calls."""
+    G, B, n = 3, 64, 3
+    import ddrl_amd
+    ddrl_amd.DdpgPopulation(ddrl_amd.DdpgConfig(n_agents=1, batch_norm_actor=14, batch_norm_critic=11, bn_adapt=int(adapt), force_more_update=n - 1,
+                                                replay_memory=500), init_seed=0).close()          # (refused with bn_adapt until round 3)
+    pop, agents, frozen = make_bn_pair(ora, 14, 11, G=G, seed=31, bn_adapt=adapt, inverting_grad=True)
+    st = np.random.RandomState(3).uniform(-1, 1, (G, 18)).astype(np.float32)
+    for call in range(2):
+        testing_before = [a.ann_testing.weights().copy() for a in agents]
+        sync(pop, agents, testing=testing_before)
+        idx = np.random.RandomState(70 + call).randint(0, 1000, (G, n, B)).astype(np.int32)
+        pop.update_n(n, idx)
+        for g, a in enumerate(agents):
+            for k in range(n):
+                a.update(idx[g, k], sync=False)
+                assert np.array_equal(a.ann_testing.weights(), testing_before[g])        # untouched inside the loop
+            a.sync_testing()
+        for net in range(4):
+            w = pop.weights(net)
+            for g, a in enumerate(agents):
+                assert rel_err(w[g], a.nets[net].weights()) <= 3e-4, (call, net, g, rel_err(w[g], a.nets[net].weights()))
+        act = pop.infer(st)                                                               # the acting copy followed the actor
+        for g, a in enumerate(agents):
+            assert rel_err(act[g], a.ann_testing.forward(st[g].astype(np.float64))[0]) <= 3e-4
+    pop.close()
+
+
 @pytest.mark.parametrize("bna,bnq,for_critic", [(14, 11, 1), (7, 12, 0), (22, 19, 1)])
 def test_ewc_lifecycle_with_towers(ora, bna, bnq, for_critic):
     """EWC (DODevMLP.hpp:604-758) on nets with towers: the EWC vectors hold the parameters with lr_mult != 0 only
