@@ -91,6 +91,9 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   // layer (behind its output tower) and behind the critic's input.  Per-dimension factors only: the host refuses the per-sample
   // Bernoulli mode on nets with towers.
   const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  long long *stamps = P.stamps ? P.stamps + (size_t)agent * 16 : nullptr;       // (diagnostic: tools/stamps_bn.py)
+#define BN_STAMP(i) do { if (stamps && tid == 0) stamps[i] = clock64(); } while (0)
+  BN_STAMP(0);
   auto actions_in = [&](float *src) {                      // actions into the critic's input tile: the actor's output gate (kept in
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {     // src: what the actor returned), then the critic's action-input gate
       const int row = e / A, col = e - row * A;
@@ -109,9 +112,11 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);
   __syncthreads();
   fwd_net_bn(na, na.L(), w_at, tmode, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);
+  BN_STAMP(1);
   actions_in(M.topa);
   __syncthreads();
   fwd_net_bn(nq, nq.L(), w_qt, tmode, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
+  BN_STAMP(2);
   // ---- TD targets (:386-405) ----
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
   int trow;
@@ -121,8 +126,10 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   }
   __syncthreads();
   if (P.qt_out && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];
+  BN_STAMP(3);
   // ---- critic update: qnn->learn_batch(s, a, y, 1)  (:408; MLP.hpp:468-485) ----
   fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
+  BN_STAMP(4);
   if (tid < DDRL_MB) {
     const float df = tid < B ? M.topq[tid * ldq] - M.yv[tid] : 0.f;
     float sq = df * df;
@@ -132,6 +139,7 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   }
   __syncthreads();
   bwd_net_bn<DW_STORE>(nq, w_q, g_q, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, 0, 0, none, wave, lane, tid);
+  BN_STAMP(5);
   __syncthreads();                                          // (workgroup-scope fence: the sweep reads other threads' gradient stores)
   // EWC (DODevMLP.hpp:636-707: Fisher average of the squared gradients, penalty towards the previous task's parameters) rides
   // in the optimiser sweep as on the tower-free path; a tower's statistics take no part (lr_mult 0: not in the EWC vectors)
@@ -141,6 +149,7 @@ ddpg_update_bn_kernel(const DdpgParams P) {
     bn_apply<EWC_Q>(nq, oq, g_q, tid);
   }
   __syncthreads();
+  BN_STAMP(6);
   // ---- actor update (:411-459) ----
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
   __syncthreads();
@@ -155,10 +164,12 @@ ddpg_update_bn_kernel(const DdpgParams P) {
     __syncthreads();
   }
   fwd_net_bn(na, na.L(), w_a, BN_TRAIN, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);   // pi = ann(s)
+  BN_STAMP(7);
   float *acts = adapt ? Z.pa : M.topa;
   actions_in(acts);
   __syncthreads();
   fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);   // Q(s, pi(s)), new critic
+  BN_STAMP(8);
   if (tid < DDRL_MB) M.topq[tid * ldq] = tid < B ? -1.0f : 0.f;            // :424-428, NOT /B
   __syncthreads();
   {
@@ -186,19 +197,24 @@ ddpg_update_bn_kernel(const DdpgParams P) {
     bwd_net_bn<DW_NONE>(nq, w_q, nullptr, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, S, A, store, wave, lane, tid);
   }
   __syncthreads();
+  BN_STAMP(9);
   // the actor's hidden tiles shared their LDS with the critic pass: rebuild them (same batch statistics, running sums untouched;
   // the input tile kept its tower's output)
   fwd_net_bn(na, na.L() - 1, w_a, BN_RECOMPUTE, B, 1, M.xa, ldxa, M.hbase, M.hstride, nullptr, 0, Z.a, wave, lane, tid);
+  BN_STAMP(10);
   bwd_net_bn<DW_STORE>(na, w_a, g_a, false, B, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, 0, 0, none, wave, lane, tid);
   __syncthreads();
+  BN_STAMP(11);
   {
     OptCtx oa = make_opt<EWC_A>(P, P.sa, na.stride(), agent, tau, omtau, (float)B, 0);
     oa.handoff = 0;
     bn_apply<EWC_A>(na, oa, g_a, tid);
   }
+  BN_STAMP(12);
   // ---- soft updates of the statistics (:462-463: after both nets have stepped and the critic's second forward) ----
   bn_soft_stats(nq, w_q, w_qt, tau, omtau, tid);
   bn_soft_stats(na, w_a, w_at, tau, omtau, tid);
+  BN_STAMP(13);
   if (tid == 0) {
     P.sq.iter[agent] += 1; P.sa.iter[agent] += 1;
     if (EWC_Q) P.sq.fisher_nbr[agent] = P.sq.fisher_nbr[agent] * P.fisher_beta + (float)B;     // DODevMLP.hpp:656

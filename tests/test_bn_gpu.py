@@ -138,6 +138,34 @@ def test_ddpg_update_with_towers(ora, bna, bnq):
     pop.close()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(bn_adapt=True, inverting_grad=True), dict(test_net=True, momentum=1), dict(ewc=100.0, ewc_for_critic=1)])
+def test_ddpg_update_with_towers_tuned_ini_nets(ora, kw):
+    """agent/deepqn/data/best-ddpg-halfcheetah.ini's nets (hidden_unit_a = 5:5:2, hidden_unit_q = 20:5:2, batch_norm 14 / 11): small
+    enough for the kernel to run them from LDS copies of the agent's parameter blocks (kernels_ddpg_bn.hip, bn_resident) -- weights,
+    running statistics, targets, gradient images; three teacher-forced updates, every blob against the oracle"""
+    G, B = 3, 64
+    pop, agents, frozen = make_bn_pair(ora, 14, 11, G=G, hidden_a=(5, 5, 2), hidden_q=(20, 5, 2), seed=77, **kw)
+    momentum = kw.get("momentum", 0)
+    for upd in range(3):
+        ws_prev = sync(pop, agents)
+        idx = np.random.RandomState(25 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        pop.update(idx)
+        last = pop.last()
+        for g, a in enumerate(agents):
+            loss, _ = a.update(idx[g])
+            qt, dact = a.last()
+            assert rel_err(last["q_targets"][g], qt) <= TOL, (upd, g, rel_err(last["q_targets"][g], qt))
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            assert rel_err(last["dact"][g], dact) <= TOL, (upd, g, rel_err(last["dact"][g], dact))
+        check_update(pop, agents, frozen, ws_prev, momentum=momentum)
+    st = np.random.RandomState(2).uniform(-1, 1, (G, 18)).astype(np.float32)
+    act = pop.infer(st)
+    sync(pop, agents)
+    for g, a in enumerate(agents):
+        assert rel_err(act[g], a.ann_testing.forward(st[g].astype(np.float64))[0]) <= TOL
+    pop.close()
+
+
 @pytest.mark.parametrize("kw", [dict(test_net=True), dict(bn_adapt=True, inverting_grad=True), dict(B=40, nstep_return=3, momentum=1),
                                 dict(hidden_act=2, actor_out_act=2, decay_v=0.01), dict(hidden_act=3, actor_out_act=0)])
 def test_ddpg_update_variants(ora, kw):
