@@ -13,6 +13,7 @@ STUB_ERR(td3_update_big_launch)
 STUB_ERR(td3_update_wide_launch)
 STUB_ERR(td3_prep_launch)
 STUB_ERR(ddpg_update_bn_launch)
+STUB_ERR(td3_update_bn_launch)
 STUB_ERR(net_forward_bn_launch)
 STUB_ERR(net_forward_launch)
 STUB_ERR(net_forward_wide_launch)

@@ -238,6 +238,196 @@ extern "C" hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// TD3Ag's update on nets with towers (agent/deepqn/include/TD3Ag.hpp:176-234: the same batch_norm_actor / _critic, test_net and
+// bn_adapt keys as DeepQNAg; :284-380): the smoothed target action through TWO target critics, both critics' learn_batch, and on
+// the agent's policy steps the actor update through the first critic, the three soft updates and the acting copy's refresh
+// (the host's, after the launch).  The same passes and sweeps as ddpg_update_bn_kernel.  A tower works in place, so a critic's
+// input tile is rebuilt from the replay rows before every critic pass.  The soft updates ride in the optimiser sweeps with
+// tau = 0 off the policy steps (nothing reads a target between a critic's step and the policy step's soft update, as in
+// kernels_td3.hip); the statistics' soft updates run at the end, on policy steps only.
+// ---------------------------------------------------------------------------------------------------------------
+// Two launches: PHASE 0 the targets and both critics, PHASE 1 the actor's step for the agents on a policy step (one kernel
+// holding both referred to the argument block often enough for the compiler to give up splitting it into registers: it was
+// copied to 1000 bytes of stack at entry and read from there).
+template <bool EWC_A, bool EWC_Q, int PHASE>
+__global__ void __launch_bounds__(DDRL_NTHREADS)
+td3_update_bn_kernel(const DdpgParams P) {
+  extern __shared__ __align__(16) float lds[];
+  const int agent = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint8_t live = P.mask ? P.mask[agent] : (uint8_t)1;
+  const uint8_t pstep = P.actor_step ? P.actor_step[agent] : (uint8_t)1;   // current_step_counter % policy_freq == 0 (:333)
+  const int len = P.rep_len[agent], head = P.rep_head[agent];
+  const float gamma = P.gamma[agent], tau = P.tau[agent], omtau = P.omtau[agent];
+  if (!live || len < 250 || len < P.B) return;             // TD3Ag.hpp:286
+  const bool actor_step = pstep != 0;
+  if (PHASE == 1 && !actor_step) return;                   // uniform over the workgroup
+  const float tau_e = actor_step ? tau : 0.f, omtau_e = actor_step ? omtau : 1.f;
+  const NetDesc &na = P.a, &nq = P.q;
+  const int S = P.S, A = P.A, B = P.B, ldxc = P.ldxc, ldxa = P.ldxa, ldq = nq.ld_top(), lda = na.ld_top();
+  const BnLds Z = bn_carve(lds, P, ldq, lda);
+  const LdsMap &M = Z.M;
+  const int *idx = P.idx + (size_t)agent * B;
+  float *w_a = P.sa.w + (size_t)agent * na.stride(), *w_at = P.sa.wt + (size_t)agent * na.stride();
+  float *w_q = P.sq.w + (size_t)agent * nq.stride(), *w_qt = P.sq.wt + (size_t)agent * nq.stride();
+  float *w_q2 = P.sq2.w + (size_t)agent * nq.stride(), *w_q2t = P.sq2.wt + (size_t)agent * nq.stride();
+  float *g_a = P.gpart_a + (size_t)agent * na.stride(), *g_q = P.gpart_q + (size_t)agent * nq.stride();
+  const float *noise = P.noise + (size_t)agent * B * A;
+  const int tmode = P.test_net ? BN_TEST : BN_TRAIN;
+  (void)tau_e; (void)omtau_e; (void)w_at; (void)w_qt; (void)w_q2t; (void)g_a; (void)tmode; (void)noise; (void)gamma;
+  auto none = [](int, int, float) {};
+  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;     // per-dimension factors (no Bernoulli mode with towers)
+  float *q1n = M.nrew;                                     // Q1'(s', a') per row (the n-step scratch: TD3Ag has no n-step targets)
+  // actions into the critic's input tile: the actor's output gate, (target pass) the smoothing noise and the clip to [-1, 1]
+  // (:307-310), then the critic's action-input gate.  keep: the gated action is written back to src (the actor's own output)
+  auto actions_in = [&](float *src, bool smooth, bool keep) __attribute__((always_inline)) {
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
+      const int row = e / A, col = e - row * A;
+      float a = src[row * lda + col];
+      if (agate) a *= agate[col];
+      if (smooth && row < B) a = fminf(fmaxf(a + noise[row * A + col], -1.f), 1.f);
+      if (keep) src[row * lda + col] = a;
+      if (agate) a *= agate[col];
+      M.xc[row * ldxc + S + col] = a;
+    }
+  };
+
+  if constexpr (PHASE == 0) {
+  // ---- a' = clip(ann_target(s') + eps, -1, 1) (:304-310), Q1', Q2' (:313-314) ----
+  gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);
+  __syncthreads();
+  fwd_net_bn(na, na.L(), w_at, tmode, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);
+  actions_in(M.topa, true, false);
+  __syncthreads();
+  fwd_net_bn(nq, nq.L(), w_qt, tmode, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
+  if (tid < DDRL_MB) q1n[tid] = M.topq[tid * ldq];
+  __syncthreads();
+  gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);      // (the first target critic's input tower worked in place)
+  actions_in(M.topa, true, false);
+  __syncthreads();
+  fwd_net_bn(nq, nq.L(), w_q2t, tmode, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
+  // ---- targets: r, or r + gamma min(Q1', Q2') (:317-326) ----
+  gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
+  int trow;
+  if (gather_owns_row(tid, trow)) {
+    const float qn = fminf(q1n[trow], M.topq[trow * ldq]);
+    M.yv[trow] = M.dn[trow] != 0.f ? M.rv[trow] : M.rv[trow] + gamma * qn;
+  }
+  __syncthreads();
+  if (P.qt_out && tid < B) P.qt_out[(size_t)agent * B + tid] = M.yv[tid];
+  // ---- both critics learn the same targets (:329-330; MLP.hpp:468-485) ----
+  // (a macro, not a lambda or a loop over the two: anything that picks between P.sq and P.sq2 at run time, or takes P's address,
+  // makes the compiler copy the kernel argument block to the stack)
+#define TD3_BN_LEARN(WK, ST, LOSS, REGATHER)                                                                                          \
+  {                                                                                                                                   \
+    if (REGATHER) {   /* the first critic's input tower worked in place */                                                            \
+      gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);                                                           \
+      __syncthreads();                                                                                                                \
+    }                                                                                                                                 \
+    fwd_net_bn(nq, nq.L(), WK, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);                    \
+    if (tid < DDRL_MB) {                                                                                                              \
+      const float df = tid < B ? M.topq[tid * ldq] - M.yv[tid] : 0.f;                                                                 \
+      float sq = df * df;                                                                                                             \
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);                                                                       \
+      if (tid == 0) LOSS[agent] = sq / (float)B * 0.5f;                                                                               \
+      M.topq[tid * ldq] = df / (float)B;                                                                                              \
+    }                                                                                                                                 \
+    __syncthreads();                                                                                                                  \
+    bwd_net_bn<DW_STORE>(nq, WK, g_q, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, 0, 0, none, wave, lane, tid);       \
+    __syncthreads();   /* workgroup-scope fence: the sweep reads other threads' gradient stores */                                    \
+    OptCtx oq = make_opt<EWC_Q>(P, ST, nq.stride(), agent, tau_e, omtau_e, (float)B, 0);                                              \
+    oq.handoff = 0;                                                                                                                   \
+    bn_apply<EWC_Q>(nq, oq, g_q, tid);                                                                                                \
+    __syncthreads();                                                                                                                  \
+  }
+  TD3_BN_LEARN(w_q, P.sq, P.loss_out, false)
+  TD3_BN_LEARN(w_q2, P.sq2, P.loss2_out, true)
+#undef TD3_BN_LEARN
+  if (tid == 0) {
+    P.sq.iter[agent] += 1;                                 // Solver::Step ++iter, both critics
+    P.sq2.iter[agent] += 1;
+    if (EWC_Q) {
+      P.sq.fisher_nbr[agent] = P.sq.fisher_nbr[agent] * P.fisher_beta + (float)B;
+      P.sq2.fisher_nbr[agent] = P.sq2.fisher_nbr[agent] * P.fisher_beta + (float)B;
+    }
+  }
+  } else {
+  // ---- delayed actor update through the FIRST critic (:333-363) ----
+  {
+    gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
+    __syncthreads();
+    const bool adapt = P.bn_adapt && na.bn_any();
+    if (adapt) {   // :339-344, the TEST-phase copy's actions
+      BnBufs nokeep = {nullptr, nullptr, nullptr, nullptr};
+      fwd_net_bn(na, na.L(), const_cast<float *>(P.a_test) + (size_t)agent * na.stride(), BN_TEST, B, 0, M.xa, ldxa, M.hbase, M.hstride,
+                 M.topa, lda, nokeep, wave, lane, tid);
+      for (int e = tid; e < DDRL_MB * lda; e += DDRL_NTHREADS) Z.pa[e] = M.topa[e];
+      __syncthreads();
+      gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);
+      __syncthreads();
+    }
+    fwd_net_bn(na, na.L(), w_a, BN_TRAIN, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);   // pi = ann(s)
+    float *acts = adapt ? Z.pa : M.topa;
+    actions_in(acts, false, true);
+    __syncthreads();
+    fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);   // Q1(s, pi(s)), new critic
+    if (tid < DDRL_MB) M.topq[tid * ldq] = tid < B ? -1.0f : 0.f;            // :351-352, NOT /B
+    __syncthreads();
+    {
+      float *topa = M.topa;
+      const int out_act = na.out_act();
+      const bool top_tower = na.bn(na.L());
+      float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
+      auto store = [=](int row, int h, float diff) {
+        const float gt = agate ? agate[h] : 1.f;
+        diff *= gt;                                                        // the critic's action-input gate
+        if (row >= B) diff = 0.f;
+        if (dact_out && row < B) dact_out[row * A + h] = diff;
+        diff *= gt;                                                        // the actor's output gate
+        float out = topa[row * lda + h];
+        if (!adapt && gt != 0.f) out /= gt;
+        topa[row * lda + h] = top_tower ? diff : act_bwd(out_act, out, diff);
+      };
+      bwd_net_bn<DW_NONE>(nq, w_q, nullptr, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, S, A, store, wave, lane, tid);
+    }
+    __syncthreads();
+    fwd_net_bn(na, na.L() - 1, w_a, BN_RECOMPUTE, B, 1, M.xa, ldxa, M.hbase, M.hstride, nullptr, 0, Z.a, wave, lane, tid);
+    bwd_net_bn<DW_STORE>(na, w_a, g_a, false, B, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, 0, 0, none, wave, lane, tid);
+    __syncthreads();
+    {
+      OptCtx oa = make_opt<EWC_A>(P, P.sa, na.stride(), agent, tau, omtau, (float)B, 0);
+      oa.handoff = 0;
+      bn_apply<EWC_A>(na, oa, g_a, tid);
+    }
+    // ---- the statistics' soft updates (:368-370), after every net has stepped and the critic's last forward ----
+    bn_soft_stats(nq, w_q, w_qt, tau, omtau, tid);
+    bn_soft_stats(nq, w_q2, w_q2t, tau, omtau, tid);
+    bn_soft_stats(na, w_a, w_at, tau, omtau, tid);
+  }
+  if (tid == 0) {
+    P.sa.iter[agent] += 1;                                 // set_iter(iter() + 1) :363
+    if (EWC_A) P.sa.fisher_nbr[agent] = P.sa.fisher_nbr[agent] * P.fisher_beta + (float)B;
+  }
+  }
+}
+
+extern "C" hipError_t td3_update_bn_launch(const DdpgParams *P, int any_actor, hipStream_t st) {
+  static LdsConfig configured[3][2];
+  const size_t lds = ddpg_update_bn_lds_bytes(P);
+  const int which = P->sa.fisher ? (P->sq.fisher ? 2 : 1) : 0;
+  for (int phase = 0; phase < (any_actor ? 2 : 1); ++phase) {
+    void (*k)(const DdpgParams);
+    if (phase == 0) k = which == 2 ? td3_update_bn_kernel<true, true, 0> : which == 1 ? td3_update_bn_kernel<true, false, 0> : td3_update_bn_kernel<false, false, 0>;
+    else k = which == 2 ? td3_update_bn_kernel<true, true, 1> : which == 1 ? td3_update_bn_kernel<true, false, 1> : td3_update_bn_kernel<false, false, 1>;
+    hipError_t e = ddrl_set_lds(k, lds, configured[which][phase]);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(P->G), dim3(DDRL_NTHREADS), lds, st, *P);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // TEST-phase evaluation of n rows per agent through one net with towers (ddrl_pop_forward_batch on such a net: the value
 // a TEST-phase copy returns, MLP.hpp:284-338, 531-579; no state changes)
 // ---------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ hipError_t replay_draw_launch(uint32_t *mt, int *pos, const int *rep_len, int G,
 hipError_t td3_update_launch(const DdpgParams *P, int force_generic, hipStream_t st);
 hipError_t td3_update_big_launch(const DdpgParams *P, int any_actor, hipStream_t st);
 hipError_t td3_update_wide_launch(const DdpgParams *P, int any_actor, hipStream_t st);
+hipError_t td3_update_bn_launch(const DdpgParams *P, int any_actor, hipStream_t st);
 hipError_t td3_prep_launch(const uint64_t *seed, uint32_t *count, const int *rep_len, int G, int B, int A,
                            const uint8_t *mask, float *noise, int draw, float sigma, float clip, double beta1,
                            double beta2, const float *lr_q2, const int *iter_q2, float *lrt_q2, hipStream_t st);
@@ -158,7 +159,6 @@ static int validate(const ddrl_ddpg_config *c) {
     }
     if ((c->batch_norm_actor & 16) && !(c->batch_norm_actor & 4))
       return ddrl_fail(DDRL_EINVAL, "batch_norm_actor %d: first_except_action is a critic layout", c->batch_norm_actor);
-    if (c->td3) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 is not served by the TD3 update");
     if (c->mini_batch_size > DDRL_MB) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs mini_batch_size <= %d (the towers couple the rows of a minibatch)", DDRL_MB);
     for (int i = 0; i < c->n_hidden_a; ++i) if (c->hidden_unit_a[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs layers of at most %d units", DDRL_MAXW);
     for (int i = 0; i < c->n_hidden_q; ++i) if (c->hidden_unit_q[i] > DDRL_MAXW) return ddrl_fail(DDRL_EINVAL, "batch_norm != 0 needs layers of at most %d units", DDRL_MAXW);
@@ -816,7 +816,9 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
   }
   int any_actor = actor_step ? 0 : 1;
   for (int g = 0; g < G && !any_actor; ++g) any_actor = actor_step[g] && (!mask || mask[g]);
-  if (h->wide) {
+  if (h->bn) {
+    HIPCHK(td3_update_bn_launch(&P, any_actor, h->stream));
+  } else if (h->wide) {
     HIPCHK(td3_update_wide_launch(&P, any_actor, h->stream));
   } else if (P.maxchunks > 1 || h->force_chunked) {
     HIPCHK(td3_update_big_launch(&P, any_actor, h->stream));
@@ -824,6 +826,9 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
     HIPCHK(td3_update_launch(&P, h->force_generic, h->stream));
   }
   if (h->profiling) HIPCHK(hipEventRecord(e1, h->stream));
+  // TD3Ag.hpp:372-375: the acting copy follows the actor inside the policy step (agents off their policy step have not moved:
+  // copying theirs again changes nothing)
+  if (h->bn && any_actor && (rc = refresh_testing(h))) return rc;
   if (idx || mask || noise || actor_step) HIPCHK(hipStreamSynchronize(h->stream));   // host arrays were read asynchronously
   return DDRL_OK;
 }

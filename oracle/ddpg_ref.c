@@ -41,10 +41,12 @@ ora_ddpg *ora_ddpg_create(const ora_ddpg_cfg *c) {
   d->ann_testing = ora_mlp_clone(d->ann);  /* :221-222 */
   ora_mlp_set_phase(d->ann_testing, 1);
   if (c->td3) {                            /* TD3Ag.hpp:221-229: a second critic of the same shape and its target */
-    d->qnn2 = ora_mlp_create(c->n_hidden_q + 1, dims, c->hidden_act, 0, c->alpha_v, c->momentum, c->decay_v);
+    d->qnn2 = ora_mlp_create_bn(c->n_hidden_q + 1, dims, c->hidden_act, 0, c->alpha_v, c->momentum, c->decay_v,
+                                c->bn_critic, c->S);             /* TD3Ag.hpp:221-222: batch_norm_critic like qnn */
     if (c->ewc >= 0. && c->ewc_for_critic >= 1)
       ora_mlp_ewc_config(d->qnn2, c->ewc, c->ewc_decay, c->ewc_fisher_beta, c->ewc_best_method);
     d->qnn_target2 = ora_mlp_clone(d->qnn2);
+    if (c->test_net) ora_mlp_set_phase(d->qnn_target2, 1);     /* TD3Ag.hpp:224-229 */
   }
   ora_mt_seed(&d->eng, c->seed);
   d->row = 2 * c->S + 2 * c->A + 2;

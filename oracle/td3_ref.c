@@ -77,6 +77,8 @@ double ora_td3_update(ora_ddpg *d, const int *idx_in, int *idx_out, const double
     ora_mlp_zero_grad(d->qnn);
     ora_mlp_zero_grad(d->ann);
     ora_mlp_forward(d->ann, all_s, B, pi);
+    if (c->bn_actor != 0 && c->bn_adapt)                  /* :339-344: the actions come from the TEST-phase copy */
+      ora_mlp_forward(d->ann_testing, all_s, B, pi);
     for (int i = 0; i < B; ++i) memcpy(sa + i * (S + A) + S, pi + i * A, sizeof(double) * A);
     ora_mlp_forward(d->qnn, sa, B, NULL);
     for (int i = 0; i < B; ++i) dq[i] = -1.0f;            /* :351-352, not divided by B */
@@ -92,6 +94,7 @@ double ora_td3_update(ora_ddpg *d, const int *idx_in, int *idx_out, const double
     ora_mlp_soft_update(d->qnn_target, d->qnn, c->tau);   /* :368-370 */
     ora_mlp_soft_update(d->qnn_target2, d->qnn2, c->tau);
     ora_mlp_soft_update(d->ann_target, d->ann, c->tau);
+    ora_ddpg_sync_testing(d);                             /* :372-375: ann_testing follows inside the policy step */
   }
 
   free(idx); free(all_s); free(all_s2); free(all_a); free(sa); free(next_a);

@@ -345,6 +345,106 @@ def test_ddpg_update_with_towers_and_gates(ora, bna, bnq, binary, adapt, inverti
     pop.close()
 
 
+@pytest.mark.parametrize("bna,bnq,kw", [(14, 11, dict()), (14, 11, dict(bn_adapt=True)), (7, 12, dict(test_net=True)),
+                                        (22, 19, dict(ewc=100.0, ewc_for_critic=1)), (0, 7, dict()), (6, 0, dict())])
+def test_td3_update_with_towers(ora, bna, bnq, kw):
+    """TD3Ag reads the same batch_norm_actor / _critic, test_net and bn_adapt keys as DeepQNAg (TD3Ag.hpp:176-234): six nets with
+    towers.  Four teacher-forced updates alternating critic-only and policy steps (policy_freq = 2), given replay indices and
+    smoothing noise: targets (min of the two target critics on the smoothed action), both losses, dQ/da, every blob of the six
+    nets (running statistics included; the targets and the acting copy move on policy steps only)."""
+    import ddrl_amd
+    from ddpg_common import synth_transitions
+    G, S, A, B = 3, 18, 6, 64
+    ha, hq = (32, 16), (24, 16)
+    cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=B, replay_memory=2000, hidden_unit_a=ha, hidden_unit_q=hq,
+                              inverting_grad=0, td3=1, policy_noise=0.2, noise_clip=0.5, policy_freq=2, batch_norm_actor=bna, batch_norm_critic=bnq,
+                              test_net=int(kw.get("test_net", False)), bn_adapt=int(kw.get("bn_adapt", False)), ewc=kw.get("ewc", -1.0),
+                              ewc_for_critic=kw.get("ewc_for_critic", 0))
+    pop = ddrl_amd.Td3Population(cfg, init_seed=bna + bnq)
+    rng = np.random.RandomState(bna * 7 + bnq)
+    alpha_a, alpha_v = 10 ** rng.uniform(-4, -2, G), 10 ** rng.uniform(-4, -2, G)
+    tau, gamma = 10 ** rng.uniform(-3, -1, G), rng.uniform(0.9, 0.999, G)
+    pop.set_hyper("alpha_a", alpha_a); pop.set_hyper("alpha_v", alpha_v); pop.set_hyper("tau_soft_update", tau); pop.set_hyper("gamma", gamma)
+    agents = []
+    for g in range(G):
+        ag = ora.Ddpg(S, A, B, ha, hq, replay_cap=2000, inverting_grad=False, gamma=float(np.float32(gamma[g])), tau=float(np.float32(tau[g])),
+                      alpha_a=float(np.float32(alpha_a[g])), alpha_v=float(np.float32(alpha_v[g])), seed=g, td3=True, batch_norm_actor=bna,
+                      batch_norm_critic=bnq, test_net=bool(kw.get("test_net", False)), bn_adapt=bool(kw.get("bn_adapt", False)),
+                      ewc=kw.get("ewc", -1.0), ewc_for_critic=kw.get("ewc_for_critic", 0))
+        rows = synth_transitions(np.random.RandomState(1000 + g), 1000, S, A)
+        pop.replay_load(g, rows)
+        for row in rows.astype(np.float64):
+            ag.insert(row[:S], row[S:S + A], row[2 * S + A], row[S + A:2 * S + A], row[2 * S + A + 1] != 0)
+        agents.append(ag)
+    # structured weights: [actor, critic, actor target, critic target, critic 2, critic 2 target]
+    frozen = {}
+    for net, twin in ((0, 2), (1, 3), (4, 5)):
+        assert pop.num_params(net) == agents[0].nets[net].np
+        w, fz = structured_weights(rng, agents[0].nets[net], 0.3, G)
+        wt = (w + (~fz) * rng.normal(0, 0.02, w.shape)).astype(np.float32).astype(np.float64)
+        pop.set_weights(net, w); pop.set_weights(twin, wt)
+        frozen[net] = frozen[twin] = fz
+
+    def sync_all():
+        ws = {n: pop.weights(n) for n in range(6)}
+        ad = {n: pop.adam(n) for n in (0, 1, 4)}
+        for g, a in enumerate(agents):
+            for n in range(6):
+                a.nets[n].set_weights(ws[n][g])
+            for n in (0, 1, 4):
+                a.nets[n].set_adam(ad[n][0][g], ad[n][1][g], int(ad[n][2][g]))
+        return ws, ad
+
+    ws, _ = sync_all()
+    for g, a in enumerate(agents):
+        a.ann_testing.set_weights(ws[0][g])                                   # the acting copy as of the last policy step
+    noise_kills = critic_kills_action_gradient(bnq)
+    for upd in range(4):
+        astep = np.full(G, upd % 2, np.uint8)
+        ws_prev, ad_prev = sync_all()
+        idx = np.random.RandomState(80 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        nz = np.clip(np.random.RandomState(90 + upd).normal(0, 0.2, (G, B, A)), -0.5, 0.5).astype(np.float32)
+        pop.update(idx=idx, noise=nz, actor_step=astep)
+        last = pop.last()
+        for g, a in enumerate(agents):
+            loss1, loss2, _ = a.update_td3(nz[g], actor_step=bool(astep[g]), idx=idx[g])
+            qt, dact = a.last()
+            assert rel_err(last["q_targets"][g], qt) <= TOL, (upd, g, rel_err(last["q_targets"][g], qt))
+            assert abs(last["loss"][g] - loss1) <= TOL * abs(loss1) and abs(last["loss2"][g] - loss2) <= TOL * abs(loss2), (upd, g)
+            if astep[g] and not noise_kills:
+                assert rel_err(last["dact"][g], dact) <= TOL, (upd, g, rel_err(last["dact"][g], dact))
+        for net in range(6):
+            w = pop.weights(net)
+            fz = frozen[net]
+            for g, a in enumerate(agents):
+                wo = a.nets[net].weights()
+                if not astep[g] and net == 0:                                 # off the policy step the actor stands still ...
+                    assert np.array_equal(w[g], ws_prev[net][g]), (upd, net, g)
+                    continue
+                if not astep[g] and net in (2, 3, 5):                         # ... and so do the targets' parameters; their TRAIN-phase
+                    assert np.array_equal(w[g][~fz], ws_prev[net][g][~fz]), (upd, net, g)     # forwards still move their statistics
+                    assert not fz.any() or rel_err(w[g][fz], wo[fz]) <= TOL, ("target statistics", upd, net, g)
+                    continue
+                if noise_kills and net in (0, 2):
+                    assert not fz.any() or rel_err(w[g][fz], wo[fz]) <= TOL
+                    continue
+                assert not fz.any() or rel_err(w[g][fz], wo[fz]) <= TOL, ("statistics", upd, net, g, rel_err(w[g][fz], wo[fz]))
+                wmax = np.max(np.abs(wo[~fz]))
+                assert np.mean(np.abs(w[g][~fz] - wo[~fz]) <= TOL * wmax) >= 0.995, ("weights", upd, net, g)
+        for net in (0, 1, 4):
+            it = pop.adam(net)[2]
+            for g in range(G):
+                assert it[g] == ad_prev[net][2][g] + (1 if (net != 0 or astep[g]) else 0)
+    st = np.random.RandomState(2).uniform(-1, 1, (G, S)).astype(np.float32)
+    act = pop.infer(st)                                                       # the last update was a policy step: the acting copy followed
+    wa = pop.weights(0)
+    for g, a in enumerate(agents):
+        if noise_kills:                                                       # (the two actors stepped on different rounding noise)
+            a.ann_testing.set_weights(wa[g])
+        assert rel_err(act[g], a.ann_testing.forward(st[g].astype(np.float64))[0]) <= TOL
+    pop.close()
+
+
 @pytest.mark.parametrize("adapt", [True, False])
 def test_fupd_loop_with_towers(ora, adapt):
     """force_more_update > 0 on tower nets (DeepQNAg.hpp:341, 415-420, 469-472): the passes of one end_episode run back to back,
