@@ -109,6 +109,32 @@ def test_td3_agents_follow_reference_schedule(ora, tmp_path):
     ag.close()
 
 
+def test_td3_agents_with_towers(tmp_path):
+    """the front end over an ini with TD3Ag's batch_norm keys (TD3Ag.hpp:176-181): loads, acts through the TEST-phase acting copy,
+    keeps the reference's update schedule (both critics every stored transition, the actor every policy_freq-th) and stays
+    finite; the arithmetic is held to the oracle in tests/test_bn_gpu.py::test_td3_update_with_towers"""
+    import ddrl_amd
+    G, S, A, pf = 2, 5, 2, 2
+    ini = os.path.join(str(tmp_path), "td3bn.ini")
+    with open(ini, "w") as f:
+        f.write(INI.format(pn=0.2, pf=pf).replace("batch_norm_critic=0", "batch_norm_critic=11").replace("batch_norm_actor=0", "batch_norm_actor=14")
+                .replace("bn_adapt=false", "bn_adapt=true"))
+    ag = ddrl_amd.Td3Agents(ini, G, S, A, seed=5)
+    rng = np.random.RandomState(1)
+    ag.start_episode(rng.uniform(-1, 1, (G, S)).astype(np.float32), True)
+    steps = 300
+    for t in range(steps):
+        act = ag.run(rng.normal(0, 1, G).astype(np.float32), rng.uniform(-1, 1, (G, S)).astype(np.float32), True,
+                     np.zeros(G, bool), np.full(G, t == steps - 1))
+        assert np.all(np.isfinite(act)) and np.all(np.abs(act) <= 1.0)
+    ag.end_episode(True)
+    itq, itq2, ita = ag.pop.adam(1)[2], ag.pop.adam(4)[2], ag.pop.adam(0)[2]
+    assert list(itq) == list(itq2) and itq[0] >= 40 and abs(int(ita[0]) * pf - int(itq[0])) <= pf
+    for net in range(6):
+        assert np.all(np.isfinite(ag.pop.weights(net)))
+    ag.close()
+
+
 def test_td3_c_flavour(tmp_path):
     """the reference's libddrl-td3 calls (ddpg.cpp built with WANT_TD3), here under the TD3Ag_ prefix"""
     import ddrl_amd
