@@ -433,7 +433,7 @@ extern "C" hipError_t td3_update_bn_launch(const DdpgParams *P, int any_actor, h
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DDRL_NTHREADS)
 net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float *__restrict__ X, float *__restrict__ out, int n, int ldh,
-                      const float *__restrict__ sgate, int S, const float *__restrict__ agate, int A, int gate_out) {
+                      const float *__restrict__ sgate, int S, const float *__restrict__ agate, int A, int gate_out, const GateMode gm) {
   extern __shared__ __align__(16) float lds[];
   const int chunk = blockIdx.x, agent = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -444,8 +444,12 @@ net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float
   for (int e = tid; e < DDRL_MB * ldx; e += DDRL_NTHREADS) {
     const int row = e / ldx, col = e - row * ldx;
     float v = (row < rows && col < d0) ? xin[(size_t)(row0 + row) * d0 + col] : 0.f;
-    if (sgate && col < S) v *= sgate[(size_t)agent * S + col];                          // per-dimension gates (no Bernoulli mode with towers)
-    else if (agate && !gate_out && col >= S && col < S + A) v *= agate[(size_t)agent * A + col - S];
+    // the Developmental layers: per-dimension factors or per-sample Bernoulli gates (the reference runs its Developmental tests
+    // over every batch_norm code, CaffeUtest.cpp:620, 693, 805, 917); the state layer sits ahead of an input tower
+    if (sgate && col < S)
+      v *= ddrl_gate_factor(sgate[(size_t)agent * S + col], gm.st_bern, gm.st_scale, gm.seed, gm.draw, agent, GS_BATCH_S, row0 + row, col);
+    else if (agate && !gate_out && col >= S && col < S + A)
+      v *= ddrl_gate_factor(agate[(size_t)agent * A + col - S], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_BATCH_A, row0 + row, col - S);
     x[e] = v;
   }
   __syncthreads();
@@ -455,18 +459,23 @@ net_forward_bn_kernel(const NetDesc nd, const float *__restrict__ w, const float
   float *o = out + (size_t)agent * n * dl;
   for (int e = tid; e < DDRL_MB * dl; e += DDRL_NTHREADS) {
     const int row = e / dl, col = e - row * dl;
-    if (row < rows) o[(size_t)(row0 + row) * dl + col] = top[row * ldt + col] * (agate && gate_out ? agate[(size_t)agent * A + col] : 1.f);
+    if (row < rows) {
+      float v = top[row * ldt + col];                       // the action layer sits behind an output tower
+      if (agate && gate_out)
+        v *= ddrl_gate_factor(agate[(size_t)agent * A + col], gm.ac_bern, gm.ac_scale, gm.seed, gm.draw, agent, GS_BATCH_A, row0 + row, col);
+      o[(size_t)(row0 + row) * dl + col] = v;
+    }
   }
 }
 
 extern "C" hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
-                                            const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st) {
+                                            const float *sgate, int S, const float *agate, int A, int gate_out, const GateMode *gm, hipStream_t st) {
   static LdsConfig conf;
   int ldh = 4;
   for (int l = 1; l < nd->L_; ++l) ldh = std::max(ldh, nd->ld_[l]);
   const size_t lds = ((size_t)(nd->L_ - 1) * DDRL_MB * ldh + (size_t)DDRL_MB * (nd->ld_[0] + nd->ld_[nd->L_])) * sizeof(float);
   hipError_t e = ddrl_set_lds(net_forward_bn_kernel, lds, conf);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(net_forward_bn_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out, n, ldh, sgate, S, agate, A, gate_out);
+  hipLaunchKernelGGL(net_forward_bn_kernel, dim3((n + DDRL_MB - 1) / DDRL_MB, G), dim3(DDRL_NTHREADS), lds, st, *nd, w, X, out, n, ldh, sgate, S, agate, A, gate_out, *gm);
   return hipGetLastError();
 }

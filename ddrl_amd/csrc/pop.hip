@@ -37,7 +37,7 @@ hipError_t ddpg_update_loop8_launch(const DdpgParams *P, hipStream_t st);
 hipError_t ddpg_update_bn_launch(const DdpgParams *P, hipStream_t st);
 size_t ddpg_update_bn_lds_bytes(const DdpgParams *P);
 hipError_t net_forward_bn_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
-                                 const float *sgate, int S, const float *agate, int A, int gate_out, hipStream_t st);
+                                 const float *sgate, int S, const float *agate, int A, int gate_out, const GateMode *gm, hipStream_t st);
 hipError_t infer_launch(const NetDesc *nd, const float *w, const float *states, float *actions,
                         const float *in_gate, const float *out_gate, const GateMode *gm, int G, hipStream_t st);
 hipError_t net_forward_launch(const NetDesc *nd, const float *w, const float *X, float *out, int n, int G,
@@ -641,7 +641,7 @@ extern "C" int ddrl_pop_forward_batch(ddrl_pop_t *h, int net, int n, const float
   hipError_t e = hipMemcpyAsync(dx, x, G * n * d0 * sizeof(float), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess)
     e = towers ? net_forward_bn_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, sg, h->cfg.nb_sensors, ag, h->cfg.nb_motors,
-                                       actor ? 1 : 0, h->stream) :
+                                       actor ? 1 : 0, &gm, h->stream) :
         wide ? net_forward_wide_launch(&t->nd, net_weights(h, net), dx, dout, dscr, n, h->G, sg, h->cfg.nb_sensors, ag,
                                        h->cfg.nb_motors, actor ? 1 : 0, &gm, h->stream)
              : net_forward_launch(&t->nd, net_weights(h, net), dx, dout, n, h->G, sg, h->cfg.nb_sensors, ag, h->cfg.nb_motors,
@@ -685,7 +685,8 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   h->P.mask = dmask;
   h->P.sgate = h->gates_on ? h->d_sgate : nullptr;
   h->P.agate = h->gates_on ? h->d_agate : nullptr;
-  if (h->gates_on && bernoulli_gates(h) && h->bn) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served together with BatchNorm towers");
+  if (h->gates_on && bernoulli_gates(h) && h->bn)
+    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the update of nets with BatchNorm towers (inference and forward_batch are)");
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
   h->P.nupd = per_launch;
@@ -771,6 +772,8 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   DDPG_ONLY(h);
   if (h->nnets != 3) return ddrl_fail(DDRL_ESTATE, "not a TD3 population (ddrl_td3_create)");
+  if (h->gates_on && bernoulli_gates(h) && h->bn)
+    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the update of nets with BatchNorm towers (inference and forward_batch are)");
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;
@@ -925,7 +928,6 @@ extern "C" int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *act
 // *_scale divides a passed value by w.  seed starts the counter-based draw stream again.
 extern "C" int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed) {
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
-  if (h->bn && (st_bernoulli || ac_bernoulli)) return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served together with BatchNorm towers");
   h->gm.st_bern = st_bernoulli ? 1 : 0; h->gm.st_scale = st_scale ? 1 : 0;
   h->gm.ac_bern = ac_bernoulli ? 1 : 0; h->gm.ac_scale = ac_scale ? 1 : 0;
   h->gm.seed = seed; h->gm.draw = 0;
@@ -961,11 +963,32 @@ static void dev_view(const ddrl_pop *h, int net, int ignore_null_lr, bool &actor
   na = counted && h->ac_layer ? h->ac_control.size() : 0;
 }
 
+// the flat positions of a net's lr_mult-0 blobs -- a tower's [mean_sum, var_sum, factor] -- which number_of_parameters(true) /
+// copyWeightsTo(w, true) / copyWeightsFrom(w, true) leave out (MLP.hpp:610-676; the reference's Developmental tests copy through
+// that view on every batch_norm code, CaffeUtest.cpp:646-656)
+static std::vector<char> null_lr_mask(const NetDesc &nd, bool ignore_null_lr) {
+  std::vector<char> m(nd.np, 0);
+  if (!ignore_null_lr) return m;
+  size_t k = 0;
+  for (int l = 0; l <= nd.L(); ++l) {
+    if (nd.bn(l)) {
+      const int C = nd.bn_c(l);
+      for (int c = 0; c < 2 * C + 1; ++c) m[k++] = 1;
+      if (nd.bn_scale()) k += C;
+      if (nd.bn_bias()) k += C;
+    }
+    if (l == nd.L()) break;
+    k += (size_t)nd.d(l + 1) * nd.d(l) + nd.d(l + 1);
+  }
+  return m;
+}
+
 extern "C" int ddrl_pop_dev_num_params(ddrl_pop_t *h, int net, int ignore_null_lr, int *n) {
   if (!h || !n || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   bool actor; size_t ns, na;
   dev_view(h, net, ignore_null_lr, actor, ns, na);
-  *n = train_net(h, net)->nd.np + (int)(ns + na);
+  const std::vector<char> skip = null_lr_mask(train_net(h, net)->nd, ignore_null_lr != 0);
+  *n = train_net(h, net)->nd.np - (int)std::count(skip.begin(), skip.end(), (char)1) + (int)(ns + na);
   return DDRL_OK;
 }
 
@@ -973,7 +996,9 @@ extern "C" int ddrl_pop_dev_get_weights(ddrl_pop_t *h, int net, int ignore_null_
   if (!h || !flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   bool actor; size_t ns, na;
   dev_view(h, net, ignore_null_lr, actor, ns, na);
-  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors, np = train_net(h, net)->nd.np, n = np + ns + na;
+  const std::vector<char> skip = null_lr_mask(train_net(h, net)->nd, ignore_null_lr != 0);
+  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors, np = train_net(h, net)->nd.np;
+  const size_t n = np - (size_t)std::count(skip.begin(), skip.end(), (char)1) + ns + na;
   std::vector<double> w(G * np), sg(h->gate_w_s), ag(h->gate_w_a);
   sg.resize(G * S, 1.); ag.resize(G * A, 1.);
   int rc = ddrl_pop_get_weights(h, net, w.data());
@@ -983,7 +1008,7 @@ extern "C" int ddrl_pop_dev_get_weights(ddrl_pop_t *h, int net, int ignore_null_
     size_t k = 0;
     if (!actor) for (size_t i = 0; i < na; ++i) o[k++] = ag[g * A + h->ac_control[i]];
     for (size_t i = 0; i < ns; ++i) o[k++] = sg[g * S + h->st_control[i]];
-    for (size_t i = 0; i < np; ++i) o[k++] = w[g * np + i];
+    for (size_t i = 0; i < np; ++i) if (!skip[i]) o[k++] = w[g * np + i];
     if (actor) for (size_t i = 0; i < na; ++i) o[k++] = ag[g * A + h->ac_control[i]];
   }
   return DDRL_OK;
@@ -993,16 +1018,19 @@ extern "C" int ddrl_pop_dev_set_weights(ddrl_pop_t *h, int net, int ignore_null_
   if (!h || !flat || bad_net(h, net)) return ddrl_fail(DDRL_EINVAL, "bad argument");
   bool actor; size_t ns, na;
   dev_view(h, net, ignore_null_lr, actor, ns, na);
-  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors, np = train_net(h, net)->nd.np, n = np + ns + na;
+  const std::vector<char> skip = null_lr_mask(train_net(h, net)->nd, ignore_null_lr != 0);
+  const size_t nskip = (size_t)std::count(skip.begin(), skip.end(), (char)1);
+  const size_t G = h->G, S = h->cfg.nb_sensors, A = h->cfg.nb_motors, np = train_net(h, net)->nd.np, n = np - nskip + ns + na;
   std::vector<double> w(G * np), sg(h->gate_w_s), ag(h->gate_w_a);
   sg.resize(G * S, 1.); ag.resize(G * A, 1.);
   int rc;
+  if (nskip && (rc = ddrl_pop_get_weights(h, net, w.data()))) return rc;     // the blobs the view leaves out stay as they are
   for (size_t g = 0; g < G; ++g) {
     const double *o = flat + g * n;
     size_t k = 0;
     if (!actor) for (size_t i = 0; i < na; ++i) ag[g * A + h->ac_control[i]] = o[k++];
     for (size_t i = 0; i < ns; ++i) sg[g * S + h->st_control[i]] = o[k++];
-    for (size_t i = 0; i < np; ++i) w[g * np + i] = o[k++];
+    for (size_t i = 0; i < np; ++i) if (!skip[i]) w[g * np + i] = o[k++];
     if (actor) for (size_t i = 0; i < na; ++i) ag[g * A + h->ac_control[i]] = o[k++];
   }
   if ((rc = ddrl_pop_set_weights(h, net, w.data()))) return rc;

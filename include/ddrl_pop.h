@@ -67,7 +67,7 @@ typedef struct {
   int    nstep_return;             /* agent.nstep_return (DeepQNAg.hpp:360-373, 394-402) */
   int    batch_norm_actor, batch_norm_critic;  /* agent.batch_norm_actor / _critic: the bit-field of MLP.hpp:53-79 (bit 0 Scale bias,
                                                 * bit 1 Scale, bits 2-4 where the towers sit); != 0: mini_batch_size <= 64,
-                                                * widths <= 128, no Bernoulli gates (kernels_ddpg_bn.hip); served for DDPG and TD3 handles; EWC is served: its vectors leave the towers'
+                                                * widths <= 128, no Bernoulli gates in the update (kernels_ddpg_bn.hip); served for DDPG and TD3 handles; EWC is served: its vectors leave the towers'
                                                 * running statistics out (lr_mult 0: DODevMLP.hpp:616, 641, 679) */
   double gamma;                    /* agent.gamma */
   double tau_soft_update, alpha_a, alpha_v, decay_v;
@@ -204,7 +204,8 @@ int ddrl_pop_get_gates(ddrl_pop_t *h, double *state_gate, double *action_gate);
  * pass of every layer instance draws its own mask, a backward pass re-creates its forward pass's mask (counter-based
  * generator keyed on seed / pass / agent / layer instance / row / dimension: the fork's generator is unknown, only the
  * pass rates are pinned).  Served by every DDPG / TD3 update path (one-tile, chunked, layer-by-layer), NFAC, infer and
- * forward_batch; DDRL_EINVAL together with BatchNorm towers (the per-dimension gates of ddrl_pop_set_gates are served there). */
+ * forward_batch.  On nets with BatchNorm towers infer and forward_batch serve it; their UPDATE answers DDRL_EINVAL while it is
+ * set (the per-dimension gates of ddrl_pop_set_gates are served there). */
 int ddrl_pop_set_gate_mode(ddrl_pop_t *h, int st_bernoulli, int st_scale, int ac_bernoulli, int ac_scale, uint32_t seed);
 /* DODevMLP's view of a net's parameters: after DODevMLP::exploit (DODevMLP.hpp:216-401) the gate weights are blobs of the
  * net, so number_of_parameters / copyWeightsTo / copyWeightsFrom (MLP.hpp:610-676) count and carry them:

@@ -282,8 +282,12 @@ def test_reference_ini_loads_and_updates(tmp_path):
     act = pop.infer(np.random.RandomState(1).uniform(-1, 1, (4, 18)).astype(np.float32))
     assert np.all(np.isfinite(act))
     pop.set_gates(np.ones((4, 18)), np.ones((4, 6)))                     # per-dimension gates are served on tower nets ...
-    with pytest.raises(ddrl_amd.DdrlError, match="probabilistic gates"):   # ... the per-sample Bernoulli mode is not
-        pop.set_gate_mode(1, 0, 1, 0, 7)
+    pop.set_gate_mode(1, 0, 1, 0, 7)                                       # ... the per-sample Bernoulli mode in inference and
+    pop.set_gates(np.full((4, 18), 0.5), np.full((4, 6), 0.5))              #     forward_batch (tests/test_dev_layer_fixtures_gpu.py),
+    out = pop.forward_batch(0, np.random.RandomState(2).uniform(-1, 1, (4, 200, 18)).astype(np.float32))
+    assert 0.4 < (out == 0).mean() < 0.6
+    with pytest.raises(ddrl_amd.DdrlError, match="probabilistic gates"):   #     not in the update
+        pop.update()
     pop.close()
 
 

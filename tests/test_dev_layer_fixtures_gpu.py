@@ -18,7 +18,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-BN0_HIDDEN_TYPES = [1, 2, 3]          # the reference loops hidden_layer (the hidden layer TYPE) over 1..3; batch_norm 0 is the case served here
+BN0_HIDDEN_TYPES = [1, 2, 3]          # the reference loops hidden_layer (the hidden layer TYPE) over 1..3 ...
+BATCH_NORMS = [0, 4, 6, 7, 8, 10, 11, 12, 14, 15]      # ... and batch_norm over these codes (CaffeUtest.cpp:620, 693, 805, 917).  With towers the
+# library evaluates forward_batch as a TEST-phase copy would (running statistics, here a fresh net's), the reference's test its TRAIN-phase
+# nets on the batch statistics: the properties held -- the gated twin equals the plain net at w = 1, an action passes at its rate and is
+# exactly 0 otherwise, the parameter views and their order -- do not depend on which statistics normalise.  The views are
+# number_of_parameters(true) / copyWeightsTo(w, true), as in the reference's tests: a tower's lr_mult-0 statistics are not in them.
 
 
 def grid_inputs(rng, G, dims, points):
@@ -28,31 +33,32 @@ def grid_inputs(rng, G, dims, points):
     return np.where(rng.uniform(0, 1, (G, B, dims)) < 0.4, rng.uniform(-1, 1, (G, B, dims)), grid[None]).astype(np.float32)
 
 
+@pytest.mark.parametrize("batch_norm", BATCH_NORMS)
 @pytest.mark.parametrize("hidden_type", BN0_HIDDEN_TYPES)
-def test_developmental_layer(hidden_type):
+def test_developmental_layer(hidden_type, batch_norm):
     """CaffeUtest.cpp:619-690: MLP(1, {8}, 1) against DODevMLP(1, {8}, 1) with empty control lists (= every dimension), both gates
     probabilistic without scaling, heuristic 0 (the default)."""
     import ddrl_amd
     G, B = 2, 400
     cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=1, nb_motors=1, mini_batch_size=16, replay_memory=500, hidden_unit_a=(8,),
-                              hidden_unit_q=(8,), hidden_layer_type=hidden_type, actor_output_layer_type=0)
+                              hidden_unit_q=(8,), hidden_layer_type=hidden_type, actor_output_layer_type=0, batch_norm_actor=batch_norm)
     actor = ddrl_amd.DdpgPopulation(cfg, init_seed=3)
     actor2 = ddrl_amd.DdpgPopulation(cfg, init_seed=4)
     actor2.set_gate_mode(st_bernoulli=True, st_scale=False, ac_bernoulli=True, ac_scale=False, seed=hidden_type)
     actor2.set_gate_layout([], [], learnable=True)
-    n = actor.num_params(0)
-    assert actor2.dev_num_params(0, ignore_null_lr=False) > n                     # :635
+    n = actor.dev_num_params(0, ignore_null_lr=True)                              # number_of_parameters(true): a plain MLP has no gate blobs
+    assert (actor.num_params(0) == n) == (batch_norm == 0)                        # ... and leaves a tower's statistics out
+    assert actor2.dev_num_params(0, ignore_null_lr=False) > actor.dev_num_params(0, ignore_null_lr=False)      # :635
     assert actor2.dev_num_params(0, ignore_null_lr=True) - 2 == n                 # :636
-    assert actor.dev_num_params(0) == n                                           # a plain MLP has no gate blobs
     rng = np.random.RandomState(hidden_type)
     x = grid_inputs(rng, G, 1, B)
-    w = actor.weights(0)
+    w = actor.dev_weights(0)
     w2 = actor2.dev_weights(0)
     w2[:, 1:-1] = w                                                               # :652-655
     w2[:, 0] = 1.0
     w2[:, -1] = 1.0
     actor2.set_dev_weights(0, w2)
-    assert np.array_equal(actor2.dev_weights(0), w2) and np.array_equal(actor2.weights(0), w)
+    assert np.array_equal(actor2.dev_weights(0), w2) and np.array_equal(actor2.weights(0), actor.weights(0))      # (fresh statistics on both)
     ref = actor.forward_batch(0, x)
     for forced in range(5):                                                       # :659-667
         assert np.array_equal(actor2.forward_batch(0, x), ref)
@@ -70,16 +76,18 @@ def test_developmental_layer(hidden_type):
     actor.close(); actor2.close()
 
 
+@pytest.mark.parametrize("batch_norm", BATCH_NORMS)
 @pytest.mark.parametrize("hidden_type", BN0_HIDDEN_TYPES)
-def test_shared_parameters_and_critic_order(hidden_type):
+def test_shared_parameters_and_critic_order(hidden_type, batch_norm):
     """CaffeUtest.cpp:919-1046: actor 3 -> 8 -> 4 and critic (3 + 4) -> 10 -> 5 -> 1 on st_control = 1:2, ac_control = 1:2.
     learnable_params()[0] of the actor and [1] of the critic are the SAME state-gate blob; the critic's [0] is the action-gate blob."""
     import ddrl_amd
     G, S, A = 2, 3, 4
     cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=16, replay_memory=500, hidden_unit_a=(8,),
-                              hidden_unit_q=(10, 5), hidden_layer_type=hidden_type, actor_output_layer_type=0)
+                              hidden_unit_q=(10, 5), hidden_layer_type=hidden_type, actor_output_layer_type=0, batch_norm_actor=batch_norm,
+                              batch_norm_critic=batch_norm)
     pop = ddrl_amd.DdpgPopulation(cfg, init_seed=7)
-    na, nq = pop.num_params(0), pop.num_params(1)
+    na, nq = pop.dev_num_params(0), pop.dev_num_params(1)                         # (no gate layout yet: the nets' own number_of_parameters(true))
     pop.set_gate_mode(st_bernoulli=True, st_scale=False, ac_bernoulli=True, ac_scale=False, seed=1)
     pop.set_gate_layout([1, 2], [1, 2], learnable=True)
     assert pop.dev_num_params(1) - 4 == nq                                        # :937
@@ -95,7 +103,9 @@ def test_shared_parameters_and_critic_order(hidden_type):
         assert np.array_equal(wa[:, i], wq[:, i + 2])                             # actor [0] == critic [1]: state gates
         assert np.array_equal(wa[:, -2 + i], wq[:, i])                            # critic [0]: action gates
         assert np.array_equal(wq[:, i], wq_t[:, i]) and np.array_equal(wq[:, i + 2], wq_t[:, i + 2])
-    assert np.array_equal(wq[:, 4:], pop.weights(1)) and np.array_equal(wa[:, 2:-2], pop.weights(0))
+    if batch_norm == 0:
+        assert np.array_equal(wq[:, 4:], pop.weights(1)) and np.array_equal(wa[:, 2:-2], pop.weights(0))
+    assert wq.shape[1] == nq + 4 and wa.shape[1] == na + 4
     # the other way round: written through the critic's view, read through the actor's
     wq[:, 0] = 0.25; wq[:, 3] = 0.75
     pop.set_dev_weights(1, wq)
@@ -117,16 +127,17 @@ def test_shared_parameters_and_critic_order(hidden_type):
     pop.close()
 
 
+@pytest.mark.parametrize("batch_norm", BATCH_NORMS)
 @pytest.mark.parametrize("hidden_type", BN0_HIDDEN_TYPES)
 @pytest.mark.parametrize("case", ["more_dimension", "control_restriction"])
-def test_more_dimension_and_control_restriction(hidden_type, case):
+def test_more_dimension_and_control_restriction(hidden_type, case, batch_norm):
     """CaffeUtest.cpp:692-802 (every state and action dimension gated: +3 +4 parameters, action weights 0.1 / 0.8 / 0.4 / 0.6 pass at
     those rates +- 0.1) and :804-913 (st_control = 1:2, ac_control = 1:2: +2 +2, weights 0.4 / 0.6 on actions 1, 2 +- 0.11,
     actions 0 and 3 always equal); actor 3 -> 8 -> 4, 343 rows."""
     import ddrl_amd
     G, S, A = 2, 3, 4
     cfg = ddrl_amd.DdpgConfig(n_agents=G, nb_sensors=S, nb_motors=A, mini_batch_size=16, replay_memory=500, hidden_unit_a=(8,),
-                              hidden_unit_q=(8,), hidden_layer_type=hidden_type, actor_output_layer_type=0)
+                              hidden_unit_q=(8,), hidden_layer_type=hidden_type, actor_output_layer_type=0, batch_norm_actor=batch_norm)
     actor = ddrl_amd.DdpgPopulation(cfg, init_seed=3)
     actor2 = ddrl_amd.DdpgPopulation(cfg, init_seed=9)
     actor2.set_gate_mode(st_bernoulli=True, st_scale=False, ac_bernoulli=True, ac_scale=False, seed=17 + hidden_type)
@@ -137,11 +148,11 @@ def test_more_dimension_and_control_restriction(hidden_type, case):
         actor2.set_gate_layout([1, 2], [1, 2], learnable=True)
         ns, rates, tol = 2, {1: 0.4, 2: 0.6}, 0.11
     na = len(rates)
-    n = actor.num_params(0)
+    n = actor.dev_num_params(0, True)
     assert actor2.dev_num_params(0, True) - ns - na == n                          # :708, :820
     w2 = actor2.dev_weights(0)
     w2[:, :ns] = 1.0
-    w2[:, ns:ns + n] = actor.weights(0)
+    w2[:, ns:ns + n] = actor.dev_weights(0)
     w2[:, ns + n:] = 1.0
     actor2.set_dev_weights(0, w2)
     rng = np.random.RandomState(3 * hidden_type + len(case))

@@ -230,8 +230,10 @@ def test_nfac_update_given_masks(ora):
 def test_refused_where_not_served(ora):
     import ddrl_amd
     pop, _ = make_pair(ora, G=2, hidden_a=(20, 10), hidden_q=(20, 10), n_replay=300, batch_norm_actor=14, batch_norm_critic=11)
-    with pytest.raises(ddrl_amd.DdrlError, match="BatchNorm"):
-        pop.set_gate_mode(1, 0, 1, 0, seed=1)
+    pop.set_gate_mode(1, 0, 1, 0, seed=1)                 # nets with towers: inference and forward_batch serve the Bernoulli mode ...
+    pop.set_gates(np.full((2, 18), 0.7), np.full((2, 6), 0.7))
+    with pytest.raises(ddrl_amd.DdrlError, match="BatchNorm"):        # ... the update does not
+        pop.update()
     pop.close()
 
 
