@@ -229,14 +229,16 @@ def timed_sweep(pop, G, steps, warmup, upl, ewc, barrier):
         if rem:
             pop.update_n(rem) if rem > 1 else pop.update()
 
-    # set-up, before the W warm-up steps the caller asked for: SETUP_UPDATES updates bring EWC to the state a sweep runs in
-    # (Fisher average accumulated -- its horizon is 1 / (1 - 0.999) updates --, snapshot taken, penalty live).  They are also what
-    # takes the GPU out of its idle state after the host-side replay loading: with one launch here, a short run (K = 20) measured
-    # 0.377 ms per update against 0.364 ms with these (same box; 0.350 ms at K = 200): reported as config.setup_updates.
-    run_updates(max(upl, SETUP_UPDATES // upl * upl))
+    # set-up, before the W warm-up steps the caller asked for: one launch accumulates a Fisher average, the EWC snapshot is taken
+    # from it (host-side bookkeeping with its own synchronisations: the GPU idles through it), and SETUP_UPDATES updates then
+    # run the state a sweep is in -- penalty live, Fisher average restarting -- long enough for the GPU to be back in its loaded
+    # state when the warm-up starts.  With the snapshot taken right before the warm-up instead, a short run (K = 20) measured
+    # 0.377 ms per update; with these 0.353 ms (same box; 0.350 ms at K = 200).  Reported as config.setup_updates.
+    run_updates(upl)
     if ewc:
         pop.update_best_param(np.ones(G))
         pop.ewc_setup()
+    run_updates(max(upl, SETUP_UPDATES // upl * upl))
     run_updates(warmup)
     pop.sync()
     pop.set_profiling(True)
