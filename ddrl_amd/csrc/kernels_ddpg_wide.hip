@@ -7,6 +7,7 @@
 // MFMA accumulators and runs the optimiser epilogue itself (no per-chunk partials, no apply launch).
 // Weights keep the tile-major layout, so weight fragments are still contiguous 1-KiB wave loads.
 #include "ddpg_device.h"
+#include <mutex>
 
 struct WideMap {
   LdsMap M;              // the fused kernel's tiles, here pointers into the scratch block
@@ -503,6 +504,9 @@ static hipError_t wide_launch(const DdpgParams *Pp, int td3, int any_actor, hipS
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) return wide_launch_range(P, td3, any_actor, 0, P.G, st);
+  // (the streams and events are per device, not per handle: handles driven from several host threads take turns here)
+  static std::mutex turn;
+  std::lock_guard<std::mutex> hold(turn);
   Aux &a = aux[dev];
   if (!a.made) {
     if ((e = hipEventCreateWithFlags(&a.fork, hipEventDisableTiming)) != hipSuccess) return e;
