@@ -88,20 +88,24 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   const int tmode = P.test_net ? BN_TEST : BN_TRAIN;
   auto none = [](int, int, float) {};
   // Developmental gates (DODevMLP.hpp:246-316): the state gates are gather_tile's; the action layer sits behind the actor's last
-  // layer (behind its output tower) and behind the critic's input.  Per-dimension factors only: the host refuses the per-sample
-  // Bernoulli mode on nets with towers.
+  // layer (behind its output tower) and behind the critic's input.  Per-dimension factors or per-sample Bernoulli masks: every
+  // layer instance draws under its own site id and a backward pass regenerates its forward pass's mask (ddrl_gate_factor).
   const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;
+  const int ac_bern = P.gm.ac_bern, ac_scale = P.gm.ac_scale;
+  const unsigned gseed = P.gm.seed, gdraw = P.gm.draw;
   long long *stamps = P.stamps ? P.stamps + (size_t)agent * 16 : nullptr;       // (diagnostic: tools/stamps_bn.py)
 #define BN_STAMP(i) do { if (stamps && tid == 0) stamps[i] = clock64(); } while (0)
   BN_STAMP(0);
-  auto actions_in = [&](float *src) {                      // actions into the critic's input tile: the actor's output gate (kept in
-    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {     // src: what the actor returned), then the critic's action-input gate
+  // actions into the critic's input tile: the actor's output gate, then the critic's action-input gate.  src keeps what the
+  // actor's last layer (or output tower) wrote: the Developmental layer has a top blob of its own (DODevMLP.hpp:262-268), the
+  // last activation's backward sees the ungated values
+  auto actions_in = [&](const float *src, bool target) {
+    for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, col = e - row * A;
       float a = src[row * lda + col];
       if (agate) {
-        a *= agate[col];
-        src[row * lda + col] = a;
-        a *= agate[col];
+        a *= ddrl_gate_factor(agate[col], ac_bern, ac_scale, gseed, gdraw, agent, target ? GS_ACTOR_T_OUT : GS_ACTOR_OUT, row, col);
+        a *= ddrl_gate_factor(agate[col], ac_bern, ac_scale, gseed, gdraw, agent, target ? GS_CRITIC_T_A : GS_CRITIC_A, row, col);
       }
       M.xc[row * ldxc + S + col] = a;
     }
@@ -113,7 +117,7 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   __syncthreads();
   fwd_net_bn(na, na.L(), w_at, tmode, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);
   BN_STAMP(1);
-  actions_in(M.topa);
+  actions_in(M.topa, true);
   __syncthreads();
   fwd_net_bn(nq, nq.L(), w_qt, tmode, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
   BN_STAMP(2);
@@ -166,7 +170,7 @@ ddpg_update_bn_kernel(const DdpgParams P) {
   fwd_net_bn(na, na.L(), w_a, BN_TRAIN, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);   // pi = ann(s)
   BN_STAMP(7);
   float *acts = adapt ? Z.pa : M.topa;
-  actions_in(acts);
+  actions_in(acts, false);
   __syncthreads();
   fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);   // Q(s, pi(s)), new critic
   BN_STAMP(8);
@@ -178,20 +182,20 @@ ddpg_update_bn_kernel(const DdpgParams P) {
     const bool top_tower = na.bn(na.L());
     float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
     auto store = [=](int row, int h, float diff) {
-      const float gt = agate ? agate[h] : 1.f;
-      diff *= gt;                                                        // the critic's action-input gate
-      if (inverting) {                                                   // :432-450, on the actions the critic saw
-        const float out = acts[row * lda + h];
+      const float gin = agate ? ddrl_gate_factor(agate[h], ac_bern, ac_scale, gseed, gdraw, agent, GS_CRITIC_A, row, h) : 1.f;
+      const float gt = agate ? ddrl_gate_factor(agate[h], ac_bern, ac_scale, gseed, gdraw, agent, GS_ACTOR_OUT, row, h) : 1.f;
+      diff *= gin;                                                       // the critic's action-input gate
+      if (inverting) {                                                   // :432-450, on the actions the actor's net returned (gated)
+        const float out = acts[row * lda + h] * gt;
         if (diff < 0.f) diff *= (1.0f - out) / 2.0f;
         else if (diff > 0.f) diff *= (out + 1.0f) / 2.0f;
       }
       if (row >= B) diff = 0.f;
       if (dact_out && row < B) dact_out[row * A + h] = diff;
       diff *= gt;                                                        // the actor's output gate
-      // the actor's output layer: its own blob values feed the activation's backward (the ungated ones: without bn_adapt the
-      // gate was applied in place); under an output tower the tower's backward comes first (bwd_net_bn)
-      float out = topa[row * lda + h];
-      if (!adapt && gt != 0.f) out /= gt;
+      // the actor's output layer: its own blob values (ungated) feed the activation's backward; under an output tower the
+      // tower's backward comes first (bwd_net_bn)
+      const float out = topa[row * lda + h];
       topa[row * lda + h] = top_tower ? diff : act_bwd(out_act, out, diff);
     };
     bwd_net_bn<DW_NONE>(nq, w_q, nullptr, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, S, A, store, wave, lane, tid);
@@ -276,18 +280,23 @@ td3_update_bn_kernel(const DdpgParams P) {
   const int tmode = P.test_net ? BN_TEST : BN_TRAIN;
   (void)tau_e; (void)omtau_e; (void)w_at; (void)w_qt; (void)w_q2t; (void)g_a; (void)tmode; (void)noise; (void)gamma;
   auto none = [](int, int, float) {};
-  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;     // per-dimension factors (no Bernoulli mode with towers)
+  const float *agate = P.agate ? P.agate + (size_t)agent * A : nullptr;     // per-dimension factors or per-sample Bernoulli masks
+  const int ac_bern = P.gm.ac_bern, ac_scale = P.gm.ac_scale;
+  const unsigned gseed = P.gm.seed, gdraw = P.gm.draw;
+  // Bernoulli mode: every Developmental layer instance has a mask of its own, the second critic and its target included
+  // (td3_regate_xc builds the critic's input tile with that net's sites)
+  const bool bern = (P.sgate || P.agate) && (P.gm.st_bern || P.gm.ac_bern);
+  (void)bern;
   float *q1n = M.nrew;                                     // Q1'(s', a') per row (the n-step scratch: TD3Ag has no n-step targets)
   // actions into the critic's input tile: the actor's output gate, (target pass) the smoothing noise and the clip to [-1, 1]
-  // (:307-310), then the critic's action-input gate.  keep: the gated action is written back to src (the actor's own output)
-  auto actions_in = [&](float *src, bool smooth, bool keep) __attribute__((always_inline)) {
+  // (:307-310), then the critic's action-input gate.  src keeps the ungated values (see ddpg_update_bn_kernel)
+  auto actions_in = [&](const float *src, bool smooth, int site_out, int site_in) __attribute__((always_inline)) {
     for (int e = tid; e < DDRL_MB * A; e += DDRL_NTHREADS) {
       const int row = e / A, col = e - row * A;
       float a = src[row * lda + col];
-      if (agate) a *= agate[col];
+      if (agate) a *= ddrl_gate_factor(agate[col], ac_bern, ac_scale, gseed, gdraw, agent, site_out, row, col);
       if (smooth && row < B) a = fminf(fmaxf(a + noise[row * A + col], -1.f), 1.f);
-      if (keep) src[row * lda + col] = a;
-      if (agate) a *= agate[col];
+      if (agate) a *= ddrl_gate_factor(agate[col], ac_bern, ac_scale, gseed, gdraw, agent, site_in, row, col);
       M.xc[row * ldxc + S + col] = a;
     }
   };
@@ -297,13 +306,14 @@ td3_update_bn_kernel(const DdpgParams P) {
   gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);
   __syncthreads();
   fwd_net_bn(na, na.L(), w_at, tmode, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);
-  actions_in(M.topa, true, false);
+  actions_in(M.topa, true, GS_ACTOR_T_OUT, GS_CRITIC_T_A);
   __syncthreads();
   fwd_net_bn(nq, nq.L(), w_qt, tmode, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
   if (tid < DDRL_MB) q1n[tid] = M.topq[tid * ldq];
   __syncthreads();
-  gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);      // (the first target critic's input tower worked in place)
-  actions_in(M.topa, true, false);
+  if (bern) td3_regate_xc(P, S, A, ldxc, agent, idx, B, head, true, M, tid, GS_CRITIC2_T_S, 0);
+  else gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, true, M, tid);      // (the first target critic's input tower worked in place)
+  actions_in(M.topa, true, GS_ACTOR_T_OUT, GS_CRITIC2_T_A);
   __syncthreads();
   fwd_net_bn(nq, nq.L(), w_q2t, tmode, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);
   // ---- targets: r, or r + gamma min(Q1', Q2') (:317-326) ----
@@ -321,7 +331,8 @@ td3_update_bn_kernel(const DdpgParams P) {
 #define TD3_BN_LEARN(WK, ST, LOSS, REGATHER)                                                                                          \
   {                                                                                                                                   \
     if (REGATHER) {   /* the first critic's input tower worked in place */                                                            \
-      gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);                                                           \
+      if (bern) td3_regate_xc(P, S, A, ldxc, agent, idx, B, head, false, M, tid, GS_CRITIC2_S, GS_CRITIC2_A_REPLAY);                  \
+      else gather_tile(P, S, A, ldxc, ldxa, agent, idx, B, head, false, M, tid);                                                      \
       __syncthreads();                                                                                                                \
     }                                                                                                                                 \
     fwd_net_bn(nq, nq.L(), WK, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);                    \
@@ -368,7 +379,7 @@ td3_update_bn_kernel(const DdpgParams P) {
     }
     fwd_net_bn(na, na.L(), w_a, BN_TRAIN, B, 0, M.xa, ldxa, M.hbase, M.hstride, M.topa, lda, Z.a, wave, lane, tid);   // pi = ann(s)
     float *acts = adapt ? Z.pa : M.topa;
-    actions_in(acts, false, true);
+    actions_in(acts, false, GS_ACTOR_OUT, GS_CRITIC_A);
     __syncthreads();
     fwd_net_bn(nq, nq.L(), w_q, BN_TRAIN, B, 0, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, wave, lane, tid);   // Q1(s, pi(s)), new critic
     if (tid < DDRL_MB) M.topq[tid * ldq] = tid < B ? -1.0f : 0.f;            // :351-352, NOT /B
@@ -379,13 +390,13 @@ td3_update_bn_kernel(const DdpgParams P) {
       const bool top_tower = na.bn(na.L());
       float *dact_out = P.dact_out ? P.dact_out + (size_t)agent * B * A : nullptr;
       auto store = [=](int row, int h, float diff) {
-        const float gt = agate ? agate[h] : 1.f;
-        diff *= gt;                                                        // the critic's action-input gate
+        const float gin = agate ? ddrl_gate_factor(agate[h], ac_bern, ac_scale, gseed, gdraw, agent, GS_CRITIC_A, row, h) : 1.f;
+        const float gt = agate ? ddrl_gate_factor(agate[h], ac_bern, ac_scale, gseed, gdraw, agent, GS_ACTOR_OUT, row, h) : 1.f;
+        diff *= gin;                                                       // the critic's action-input gate
         if (row >= B) diff = 0.f;
         if (dact_out && row < B) dact_out[row * A + h] = diff;
         diff *= gt;                                                        // the actor's output gate
-        float out = topa[row * lda + h];
-        if (!adapt && gt != 0.f) out /= gt;
+        const float out = topa[row * lda + h];
         topa[row * lda + h] = top_tower ? diff : act_bwd(out_act, out, diff);
       };
       bwd_net_bn<DW_NONE>(nq, w_q, nullptr, false, B, M.xc, ldxc, M.hbase, M.hstride, M.topq, ldq, Z.q, S, A, store, wave, lane, tid);

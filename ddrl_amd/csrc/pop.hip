@@ -685,8 +685,6 @@ static int ddpg_update_n(ddrl_pop *h, int n, const int32_t *idx, const uint8_t *
   h->P.mask = dmask;
   h->P.sgate = h->gates_on ? h->d_sgate : nullptr;
   h->P.agate = h->gates_on ? h->d_agate : nullptr;
-  if (h->gates_on && bernoulli_gates(h) && h->bn)
-    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the update of nets with BatchNorm towers (inference and forward_batch are)");
   h->P.sa = h->net[0].st;
   h->P.sq = h->net[1].st;
   h->P.nupd = per_launch;
@@ -772,8 +770,6 @@ extern "C" int ddrl_pop_td3_update(ddrl_pop_t *h, const int32_t *idx, const floa
   if (!h) return ddrl_fail(DDRL_EINVAL, "NULL handle");
   DDPG_ONLY(h);
   if (h->nnets != 3) return ddrl_fail(DDRL_ESTATE, "not a TD3 population (ddrl_td3_create)");
-  if (h->gates_on && bernoulli_gates(h) && h->bn)
-    return ddrl_fail(DDRL_EINVAL, "probabilistic gates are not served by the update of nets with BatchNorm towers (inference and forward_batch are)");
   int rc = set_device(h);
   if (rc) return rc;
   const int G = h->G, B = h->cfg.mini_batch_size, A = h->cfg.nb_motors;

@@ -67,7 +67,7 @@ typedef struct {
   int    nstep_return;             /* agent.nstep_return (DeepQNAg.hpp:360-373, 394-402) */
   int    batch_norm_actor, batch_norm_critic;  /* agent.batch_norm_actor / _critic: the bit-field of MLP.hpp:53-79 (bit 0 Scale bias,
                                                 * bit 1 Scale, bits 2-4 where the towers sit); != 0: mini_batch_size <= 64,
-                                                * widths <= 128, no Bernoulli gates in the update (kernels_ddpg_bn.hip); served for DDPG and TD3 handles; EWC is served: its vectors leave the towers'
+                                                * widths <= 128 (kernels_ddpg_bn.hip); served for DDPG and TD3 handles; the developmental gates (both modes) and EWC are served: its vectors leave the towers'
                                                 * running statistics out (lr_mult 0: DODevMLP.hpp:616, 641, 679) */
   double gamma;                    /* agent.gamma */
   double tau_soft_update, alpha_a, alpha_v, decay_v;

@@ -44,6 +44,8 @@ struct ora_mlp {
   int rq_n, rq_B[ORA_ROWQ];
   double *rq_in[ORA_ROWQ], *rq_out[ORA_ROWQ];
   double *row_in, *row_out;
+  double *pre_out;             /* the net's output ahead of the output gate (the Developmental layer has a top blob of its own,
+                                * DODevMLP.hpp:262-268: the last activation's backward sees the ungated values) */
   /* EWC (DODevMLP.hpp:803-822) */
   double ewc, ewc_decay, ewc_decay_mult, fisher_beta, fisher_nbr, best_score;
   int best_method, last_update_best;
@@ -139,6 +141,7 @@ void ora_mlp_free(ora_mlp *n) {
   free(n->w); free(n->g); free(n->m); free(n->v);
   free(n->in_gate); free(n->out_gate); free(n->frozen);
   ORA_ROWQ_DROP(n);
+  free(n->pre_out);
   for (int i = 0; i < n->rq_n; ++i) { free(n->rq_in[i]); free(n->rq_out[i]); }
   free(n->fisher); free(n->prev_fisher); free(n->best_param); free(n->best_prev);
   free(n);
@@ -165,6 +168,7 @@ ora_mlp *ora_mlp_clone(const ora_mlp *s) {
   if (s->frozen) { n->frozen = (unsigned char *)malloc(s->np ? s->np : 1); memcpy(n->frozen, s->frozen, s->np); }
   n->B = 0;
   n->rq_n = 0; n->row_in = n->row_out = NULL;
+  n->pre_out = NULL;
   return n;
 }
 
@@ -322,9 +326,13 @@ void ora_mlp_forward(ora_mlp *n, const double *x, int B, double *out) {
   }
   int dl = n->d[n->L];
   if (n->bn_rank[n->L]) bn_forward(n, n->L, B);
-  if (n->row_out || n->out_gate)
+  free(n->pre_out);
+  n->pre_out = NULL;
+  if (n->row_out || n->out_gate) {
+    n->pre_out = dupv(n->act[n->L], B * dl);
     for (int i = 0; i < B; ++i)
       for (int o = 0; o < dl; ++o) n->act[n->L][i * dl + o] *= n->row_out ? n->row_out[i * dl + o] : n->out_gate[o];
+  }
   if (out) memcpy(out, n->act[n->L], sizeof(double) * B * dl);
 }
 
@@ -350,9 +358,10 @@ void ora_mlp_backward(ora_mlp *n, const double *dout, int B, double *din) {
     if (n->row_out || n->out_gate) {
       double gte = n->row_out ? n->row_out[i] : n->out_gate[i % dl];
       if (!n->bn_rank[L]) d *= gte;
-      /* a gated-off output is 0; the activation derivative needs the pre-gate value, which for a
-       * 0 gate is irrelevant since d == 0 */
-      if (gte != 0.) y /= gte;
+      /* the activation derivative needs the pre-gate value (under a TRAIN-phase output tower d != 0 even where the row's
+       * gate is 0: the tower's backward mixes the rows of a column) */
+      if (n->pre_out) y = n->pre_out[i];
+      else if (gte != 0.) y /= gte;
     }
     dy[i] = act_bwd(type, y, d);
   }

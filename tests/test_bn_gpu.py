@@ -282,12 +282,12 @@ def test_reference_ini_loads_and_updates(tmp_path):
     act = pop.infer(np.random.RandomState(1).uniform(-1, 1, (4, 18)).astype(np.float32))
     assert np.all(np.isfinite(act))
     pop.set_gates(np.ones((4, 18)), np.ones((4, 6)))                     # per-dimension gates are served on tower nets ...
-    pop.set_gate_mode(1, 0, 1, 0, 7)                                       # ... the per-sample Bernoulli mode in inference and
-    pop.set_gates(np.full((4, 18), 0.5), np.full((4, 6), 0.5))              #     forward_batch (tests/test_dev_layer_fixtures_gpu.py),
+    pop.set_gate_mode(1, 0, 1, 0, 7)                                       # ... and so is the per-sample Bernoulli mode: inference,
+    pop.set_gates(np.full((4, 18), 0.5), np.full((4, 6), 0.5))              #     forward_batch (tests/test_dev_layer_fixtures_gpu.py)
     out = pop.forward_batch(0, np.random.RandomState(2).uniform(-1, 1, (4, 200, 18)).astype(np.float32))
     assert 0.4 < (out == 0).mean() < 0.6
-    with pytest.raises(ddrl_amd.DdrlError, match="probabilistic gates"):   #     not in the update
-        pop.update()
+    pop.update()                                                            #     and the update (test_ddpg_update_with_towers_given_masks)
+    assert all(np.all(np.isfinite(pop.weights(n))) for n in range(4))
     pop.close()
 
 
@@ -349,14 +349,80 @@ def test_ddpg_update_with_towers_and_gates(ora, bna, bnq, binary, adapt, inverti
     pop.close()
 
 
+@pytest.mark.parametrize("bna,bnq,scale,adapt,inverting", [(14, 11, 1, 0, True), (7, 12, 0, 1, True), (22, 19, 1, 1, False), (0, 7, 0, 0, False),
+                                                            (6, 0, 1, 0, True)])
+def test_ddpg_update_with_towers_given_masks(ora, bna, bnq, scale, adapt, inverting):
+    """The probabilistic Developmental layer (DODevMLP.hpp:276-304, probabilist = 0) in the update of nets with towers: per-sample
+    masks, one per layer instance, the backward passes under their forward pass's mask, the masks ahead of the input towers and
+    behind the actor's output tower.  Against the oracle fed the masks the device's generator produces (restated in
+    test_gates_prob_gpu.gate_factors; the fork's own generator is absent: parity unpinned beyond the pass rates)."""
+    from test_gates_prob_gpu import (ACTOR_OUT, ACTOR_S, ACTOR_T_OUT, ACTOR_T_S, CRITIC_A, CRITIC_A_REPLAY, CRITIC_S, CRITIC_T_A, CRITIC_T_S,
+                                     gate_factors)
+    G, B, S, A = 3, 64, 18, 6
+    pop, agents, frozen = make_bn_pair(ora, bna, bnq, G=G, seed=bna + bnq + 5, bn_adapt=adapt, inverting_grad=inverting)
+    rng = np.random.RandomState(bna * 13 + bnq)
+    sg = np.round(rng.uniform(0.4, 1, (G, S)), 2); sg[:, ::3] = 1.0
+    ag = np.round(rng.uniform(0.4, 1, (G, A)), 2); ag[:, 0] = 1.0
+    sg = sg.astype(np.float32).astype(np.float64); ag = ag.astype(np.float32).astype(np.float64)
+    pop.set_gates(sg, ag)
+    noise = critic_kills_action_gradient(bnq)
+    seed = 300 + bna
+    for upd in range(3):
+        pop.set_gate_mode(1, scale, 1, scale, seed=seed + upd)          # draw counter 0 for the coming update
+        ws_prev = sync(pop, agents)
+        idx = np.random.RandomState(25 + upd).randint(0, 1000, (G, B)).astype(np.int32)
+        for g, a in enumerate(agents):
+            F = lambda wv, site: gate_factors(wv, 1, scale, seed + upd, 0, g, site, B)
+            a.ann_target.push_row_gates(F(sg[g], ACTOR_T_S), F(ag[g], ACTOR_T_OUT), B)
+            a.qnn_target.push_row_gates(np.concatenate([F(sg[g], CRITIC_T_S), F(ag[g], CRITIC_T_A)], 1), None, B)
+            a.qnn.push_row_gates(np.concatenate([F(sg[g], CRITIC_S), F(ag[g], CRITIC_A_REPLAY)], 1), None, B)
+            a.qnn.push_row_gates(np.concatenate([F(sg[g], CRITIC_S), F(ag[g], CRITIC_A)], 1), None, B)
+            a.ann.push_row_gates(F(sg[g], ACTOR_S), F(ag[g], ACTOR_OUT), B)
+            if adapt and bna != 0:                                # the TEST-phase copy's pass (DeepQNAg.hpp:415-420): the actor's masks
+                a.ann_testing.push_row_gates(F(sg[g], ACTOR_S), F(ag[g], ACTOR_OUT), B)
+        pop.update(idx)
+        last = pop.last()
+        for g, a in enumerate(agents):
+            loss, _ = a.update(idx[g])
+            assert all(n.row_gates_pending() == 0 for n in (a.ann, a.qnn, a.ann_target, a.qnn_target, a.ann_testing))
+            qt, dact = a.last()
+            assert rel_err(last["q_targets"][g], qt) <= TOL, (upd, g, rel_err(last["q_targets"][g], qt))
+            assert abs(last["loss"][g] - loss) <= TOL * abs(loss)
+            if noise:
+                assert np.max(np.abs(dact)) <= 1e-12 and np.max(np.abs(last["dact"][g])) <= 1e-4
+            else:
+                assert rel_err(last["dact"][g], dact) <= TOL, (upd, g, rel_err(last["dact"][g], dact))
+        check_update(pop, agents, frozen, ws_prev, actor_noise=noise)
+    # w in {0, 1}: Bernoulli(w) passes never / always, so the update is the deterministic gates' bit for bit
+    res = []
+    for bern in (0, 1):
+        p2, _, _ = make_bn_pair(ora, bna, bnq, G=G, seed=bna + bnq + 5, bn_adapt=adapt, inverting_grad=inverting)
+        p2.set_gates((sg > 0.7).astype(np.float64), (ag > 0.7).astype(np.float64))
+        p2.set_gate_mode(bern, bern, bern, bern, seed=4)
+        for upd in range(2):
+            p2.update(np.random.RandomState(40 + upd).randint(0, 1000, (G, B)).astype(np.int32))
+        res.append([p2.weights(n) for n in range(4)])
+        p2.close()
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)
+    pop.close()
+
+
 @pytest.mark.parametrize("bna,bnq,kw", [(14, 11, dict()), (14, 11, dict(bn_adapt=True)), (7, 12, dict(test_net=True)),
-                                        (22, 19, dict(ewc=100.0, ewc_for_critic=1)), (0, 7, dict()), (6, 0, dict())])
+                                        (22, 19, dict(ewc=100.0, ewc_for_critic=1)), (0, 7, dict()), (6, 0, dict()),
+                                        (14, 11, dict(bern=1, scale=1)), (7, 12, dict(bern=1, scale=0, bn_adapt=True)), (6, 0, dict(bern=1, scale=1)),
+                                        (0, 7, dict(bern=1, scale=0)), (7, 12, dict(bn_adapt=True)), (22, 19, dict(bern=1, scale=1, bn_adapt=True))])
 def test_td3_update_with_towers(ora, bna, bnq, kw):
     """TD3Ag reads the same batch_norm_actor / _critic, test_net and bn_adapt keys as DeepQNAg (TD3Ag.hpp:176-234): six nets with
     towers.  Four teacher-forced updates alternating critic-only and policy steps (policy_freq = 2), given replay indices and
     smoothing noise: targets (min of the two target critics on the smoothed action), both losses, dQ/da, every blob of the six
-    nets (running statistics included; the targets and the acting copy move on policy steps only)."""
+    nets (running statistics included; the targets and the acting copy move on policy steps only).  bern: the probabilistic
+    Developmental layers on top (per-sample masks, a layer instance per net: the second critic and its target draw their own),
+    the oracle fed the masks of the device's generator."""
     import ddrl_amd
+    from test_gates_prob_gpu import (ACTOR_OUT, ACTOR_S, ACTOR_T_OUT, ACTOR_T_S, CRITIC_A, CRITIC_A_REPLAY, CRITIC_S, CRITIC_T_A, CRITIC_T_S,
+                                     gate_factors)
+    C2_T_S, C2_T_A, C2_S, C2_A_REPLAY = 17, 18, 19, 20
     from ddpg_common import synth_transitions
     G, S, A, B = 3, 18, 6, 64
     ha, hq = (32, 16), (24, 16)
@@ -403,15 +469,37 @@ def test_td3_update_with_towers(ora, bna, bnq, kw):
     for g, a in enumerate(agents):
         a.ann_testing.set_weights(ws[0][g])                                   # the acting copy as of the last policy step
     noise_kills = critic_kills_action_gradient(bnq)
+    bern, scale = kw.get("bern", 0), kw.get("scale", 0)
+    if bern:
+        sg = np.round(rng.uniform(0.4, 1, (G, S)), 2); sg[:, ::3] = 1.0
+        ag_ = np.round(rng.uniform(0.4, 1, (G, A)), 2); ag_[:, 0] = 1.0
+        sg = sg.astype(np.float32).astype(np.float64); ag_ = ag_.astype(np.float32).astype(np.float64)
+        pop.set_gates(sg, ag_)
     for upd in range(4):
         astep = np.full(G, upd % 2, np.uint8)
         ws_prev, ad_prev = sync_all()
         idx = np.random.RandomState(80 + upd).randint(0, 1000, (G, B)).astype(np.int32)
         nz = np.clip(np.random.RandomState(90 + upd).normal(0, 0.2, (G, B, A)), -0.5, 0.5).astype(np.float32)
+        if bern:
+            pop.set_gate_mode(1, scale, 1, scale, seed=500 + upd)       # draw counter 0 for the coming update
+            for g, a in enumerate(agents):
+                F = lambda wv, site: gate_factors(wv, 1, scale, 500 + upd, 0, g, site, B)
+                cat = lambda s_site, a_site: np.concatenate([F(sg[g], s_site), F(ag_[g], a_site)], 1)
+                a.ann_target.push_row_gates(F(sg[g], ACTOR_T_S), F(ag_[g], ACTOR_T_OUT), B)
+                a.qnn_target.push_row_gates(cat(CRITIC_T_S, CRITIC_T_A), None, B)
+                a.qnn_target2.push_row_gates(cat(C2_T_S, C2_T_A), None, B)
+                a.qnn.push_row_gates(cat(CRITIC_S, CRITIC_A_REPLAY), None, B)
+                a.qnn2.push_row_gates(cat(C2_S, C2_A_REPLAY), None, B)
+                if astep[g]:
+                    a.ann.push_row_gates(F(sg[g], ACTOR_S), F(ag_[g], ACTOR_OUT), B)
+                    if kw.get("bn_adapt") and bna != 0:
+                        a.ann_testing.push_row_gates(F(sg[g], ACTOR_S), F(ag_[g], ACTOR_OUT), B)
+                    a.qnn.push_row_gates(cat(CRITIC_S, CRITIC_A), None, B)
         pop.update(idx=idx, noise=nz, actor_step=astep)
         last = pop.last()
         for g, a in enumerate(agents):
             loss1, loss2, _ = a.update_td3(nz[g], actor_step=bool(astep[g]), idx=idx[g])
+            assert all(n.row_gates_pending() == 0 for n in a.nets) and a.ann_testing.row_gates_pending() == 0
             qt, dact = a.last()
             assert rel_err(last["q_targets"][g], qt) <= TOL, (upd, g, rel_err(last["q_targets"][g], qt))
             assert abs(last["loss"][g] - loss1) <= TOL * abs(loss1) and abs(last["loss2"][g] - loss2) <= TOL * abs(loss2), (upd, g)
@@ -439,6 +527,13 @@ def test_td3_update_with_towers(ora, bna, bnq, kw):
             it = pop.adam(net)[2]
             for g in range(G):
                 assert it[g] == ad_prev[net][2][g] + (1 if (net != 0 or astep[g]) else 0)
+        if noise_kills and astep.all():       # the two actors stepped on different rounding noise: the oracle's acting copy (bn_adapt
+            wa = pop.weights(0)               # reads it at the next policy step) follows the device's, like the six nets do
+            for g, a in enumerate(agents):
+                a.ann_testing.set_weights(wa[g])
+    if bern:
+        pop.close()
+        return
     st = np.random.RandomState(2).uniform(-1, 1, (G, S)).astype(np.float32)
     act = pop.infer(st)                                                       # the last update was a policy step: the acting copy followed
     wa = pop.weights(0)

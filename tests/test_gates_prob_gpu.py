@@ -227,13 +227,16 @@ def test_nfac_update_given_masks(ora):
     pop.close()
 
 
-def test_refused_where_not_served(ora):
-    import ddrl_amd
+def test_served_on_nets_with_towers(ora):
+    """nets with BatchNorm towers take the Bernoulli mode too: inference, forward_batch and the update (parity against the oracle
+    given the masks: tests/test_bn_gpu.py::test_ddpg_update_with_towers_given_masks, test_td3_update_with_towers[bern])"""
     pop, _ = make_pair(ora, G=2, hidden_a=(20, 10), hidden_q=(20, 10), n_replay=300, batch_norm_actor=14, batch_norm_critic=11)
-    pop.set_gate_mode(1, 0, 1, 0, seed=1)                 # nets with towers: inference and forward_batch serve the Bernoulli mode ...
+    pop.set_gate_mode(1, 0, 1, 0, seed=1)
     pop.set_gates(np.full((2, 18), 0.7), np.full((2, 6), 0.7))
-    with pytest.raises(ddrl_amd.DdrlError, match="BatchNorm"):        # ... the update does not
-        pop.update()
+    w0 = pop.weights(0)
+    pop.update()
+    w1 = pop.weights(0)
+    assert np.all(np.isfinite(w1)) and not np.array_equal(w0, w1)
     pop.close()
 
 
