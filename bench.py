@@ -438,10 +438,10 @@ def extra_measurements(args, S, A, B, ewc, upl, barrier, budget_s=75.0):
     try:
         ddpg_entry("agents128", 128, "mid", 96, 16, args.replay)
         ddpg_entry("small", 1024, "small", 96, 16, 2000)
-        ddpg_entry("large", 1024, "large", 16, 4, 2000)
+        ddpg_entry("large", 1024, "large", 40, 8, 2000)
         if left() > 12:
             class _A:                                   # the NFAC sweep's arguments
-                agents, steps, warmup, no_cpu, cpu_threads, cpu_seconds = 1024, 4, 1, True, 0, 0.0
+                agents, steps, warmup, no_cpu, cpu_threads, cpu_seconds = 1024, 10, 2, True, 0, 0.0
             n = nfac_measure(_A, 0, 0, 1, cpu_leg=False)
             out["nfac"] = {"workload": n["config"]["workload"], "value": n["value"], "unit": n["unit"], "ms_per_update": n["ms_per_step"],
                            "mfma_f32_frac_gradient_launch": n["roofline"]["frac"]}
@@ -454,7 +454,7 @@ def extra_measurements(args, S, A, B, ewc, upl, barrier, budget_s=75.0):
                 if left() < (6 if N == 631 else 3):
                     cm[key] = {"skipped": "time budget"}
                     continue
-                cm[key] = cmaes_measure(N, 4096, dev, 6 if dev else 4)
+                cm[key] = cmaes_measure(N, 4096, dev, 16 if dev else 4)      # (median per generation: the first decompositions start cold)
         out["cmaes"] = dict(cm, workload="config 4: CMA-ES lambda=4096 mu=2048 on one GPU, synthetic quadratic fitness")
     except Exception as e:                               # the headline line must not be lost to a secondary sweep
         out["error"] = "%s: %s" % (type(e).__name__, e)
