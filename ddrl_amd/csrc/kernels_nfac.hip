@@ -83,8 +83,8 @@ nfac_values_kernel(const NfacParams P) {
 // The scan runs sequentially in the reference's order from LDS.
 template <int MODE>
 __global__ void __launch_bounds__(256)
-nfac_scan_kernel(const NfacParams P) {
-  extern __shared__ __align__(16) float sd[];      // [T] deltas
+nfac_scan_kernel(const NfacParams P, int flag_off) {
+  extern __shared__ __align__(16) float sd[];      // [T] deltas; from sd + flag_off (floats; 0: no room) the episode-end flags
   const int agent = blockIdx.x, tid = threadIdx.x;
   if (P.mask && !P.mask[agent]) return;
   const int T = P.len[agent];
@@ -100,22 +100,28 @@ nfac_scan_kernel(const NfacParams P) {
     if (row[cr + 1] == 0.f) vt += gamma * P.nextV[ro + li];
     sd[li] = (MODE == 0 && P.lambda < 0.f) ? vt : vt - P.V[ro + li];
   }
+  uint8_t *lf = (uint8_t *)(sd + flag_off);
+  if (scan && flag_off)      // the flags beside the deltas: the walk below tests one per step (from memory: a round trip per step)
+    for (int li = tid; li < T; li += 256) lf[li] = P.endflag[ro + li];
   __syncthreads();
   if (scan) {
     // the recurrence restarts at every episode's last row, so the episodes scan independently: one thread per episode end
     // walks its episode backwards (the reference's order within an episode, bit for bit)
     const float gl = gamma * P.lambda;
-    const uint8_t *ef = P.endflag + ro;
-    for (int end = tid; end < T; end += 256) {
-      if (!(ef[end] || end == T - 1)) continue;
-      float prev = 0.f;
-      for (int li = end; li >= 0; --li) {
-        if (li != end && ef[li]) break;
-        const float d = sd[li] + prev;
-        sd[li] = d;
-        prev = gl * d;
+    auto walk = [&](const auto *ef) {
+      for (int end = tid; end < T; end += 256) {
+        if (!(ef[end] || end == T - 1)) continue;
+        float prev = 0.f;
+        for (int li = end; li >= 0; --li) {
+          if (li != end && ef[li]) break;
+          const float d = sd[li] + prev;
+          sd[li] = d;
+          prev = gl * d;
+        }
       }
-    }
+    };
+    if (flag_off) walk(lf);
+    else walk(P.endflag + ro);
   }
   __syncthreads();
   int n = 0;
@@ -350,11 +356,14 @@ extern "C" hipError_t nfac_values_launch(const NfacParams *P, int chunks, hipStr
 
 extern "C" hipError_t nfac_scan_launch(const NfacParams *P, int mode, int maxlen, hipStream_t st) {
   static LdsConfig conf0, conf1;
-  const size_t lds = (size_t)std::max(maxlen, 1) * sizeof(float);
+  const int nf = std::max(maxlen, 1);
+  size_t lds = (size_t)nf * sizeof(float);
+  int flag_off = 0;                                  // the end flags in LDS too where they fit (max_trajectory up to 32768 rows: 128 KB of deltas)
+  if (lds + (size_t)((nf + 15) & ~15) + 2048 <= 160 * 1024) { flag_off = nf; lds += (size_t)((nf + 15) & ~15); }
   hipError_t e = mode == 0 ? ddrl_set_lds(nfac_scan_kernel<0>, lds, conf0) : ddrl_set_lds(nfac_scan_kernel<1>, lds, conf1);
   if (e != hipSuccess) return e;
-  if (mode == 0) hipLaunchKernelGGL(nfac_scan_kernel<0>, dim3(P->G), dim3(256), lds, st, *P);
-  else hipLaunchKernelGGL(nfac_scan_kernel<1>, dim3(P->G), dim3(256), lds, st, *P);
+  if (mode == 0) hipLaunchKernelGGL(nfac_scan_kernel<0>, dim3(P->G), dim3(256), lds, st, *P, flag_off);
+  else hipLaunchKernelGGL(nfac_scan_kernel<1>, dim3(P->G), dim3(256), lds, st, *P, flag_off);
   return hipGetLastError();
 }
 
