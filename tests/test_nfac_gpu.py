@@ -155,6 +155,26 @@ def test_single_step_updates_teacher_forced(ora, name):
         assert list(pop.traj_len()) == [0] * G           # trajectory.clear()
 
 
+def test_long_trajectory_scan_with_flags_in_memory(ora):
+    """max_trajectory at its limit: beyond 32 358 rows the scan kernel's LDS holds the deltas only and the backward walk tests the
+    episode-end flags in memory (nfac_scan_launch); shorter launches keep the flags beside the deltas.  Same deltas either way."""
+    S, A, ha, hv = 6, 2, (16,), (16,)
+    G, maxT = 2, 32768
+    pop, agents, lrs = make_pair(ora, G, S, A, ha, hv, maxT, seed=9, update_critic_first=0, lambda_=0.9, gae=1,
+                                 number_fitted_iteration=1, stoch_iter_actor=1, stoch_iter_critic=1)
+    rng = np.random.RandomState(4)
+    for lens in ([32500, 300], [900, 32000]):             # flags in memory, flags in LDS
+        trajs = load_trajs(pop, rng, lens, S, A, n_ep=7)
+        sync_oracle(pop, agents)
+        pop.update()
+        last = pop.last()
+        for g, ag in enumerate(agents):
+            n, deltas = oracle_update(ag, *trajs[g], S, A)
+            assert rel_err(last["deltas"][g, :lens[g]], deltas) <= TOL, (lens, g, rel_err(last["deltas"][g, :lens[g]], deltas))
+            assert abs(int(last["n_pos"][g]) - n) <= max(1, lens[g] // 1000)      # deltas within rounding of 0 may fall either side
+    pop.close()
+
+
 def test_critic_first_single_steps(ora):
     """update_critic_first = 1: the advantages are taken from the critic AFTER its step."""
     S, A, ha, hv = 18, 6, (32, 32), (32, 32)
