@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 // ---- DDRL_F64_DEBUG: the fp64 debug instantiation of the fused DDPG update (`make f64`) ----
 // The SAME sources with every `float` of the device state, the LDS tiles and the arithmetic turned into `double`
@@ -293,11 +294,15 @@ struct NfacParams {
 // configured is remembered per device (a handle per GPU may live in one process).  A concurrent
 // first launch from two threads at worst sets the attribute twice.
 struct LdsConfig { size_t bytes[64] = {}; };
+// (a kernel's LdsConfig is shared by every handle of the process: handles driven from several host threads take turns here, so
+// that a smaller request never lands on top of a larger one that another thread has just recorded)
+inline std::mutex &ddrl_lds_turn() { static std::mutex m; return m; }
 template <class K>
 static inline hipError_t ddrl_set_lds(K kernel, size_t lds, LdsConfig &cfg) {
   if (lds <= 48 * 1024) return hipSuccess;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  std::lock_guard<std::mutex> hold(ddrl_lds_turn());
   if (lds > cfg.bytes[dev] || dev == 63) {
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
