@@ -51,3 +51,46 @@ def test_two_handles_two_threads(name, ha, hq, G):
         assert not isinstance(ref[k], Exception) and not isinstance(got[k], Exception), (ref[k], got[k])
         for a, b in zip(ref[k], got[k]):
             assert np.array_equal(a, b), (name, k)
+
+
+def build_nfac(G, seed):
+    import ddrl_amd
+    cfg = ddrl_amd.NfacConfig(n_agents=G, nb_sensors=18, nb_motors=6, hidden_unit_a=(32, 32), hidden_unit_v=(32, 32), max_trajectory=256,
+                              number_fitted_iteration=2, stoch_iter_actor=3, stoch_iter_critic=3)
+    cfg.set("lambda", 0.9); cfg.set("gae", 1)
+    return ddrl_amd.NfacPopulation(cfg, init_seed=seed)
+
+
+def run_nfac(pop, G, n, out, key):
+    from test_nfac_gpu import synth_traj
+    try:
+        for u in range(n):
+            for g in range(G):
+                rows, ends = synth_traj(np.random.RandomState(1000 * u + g), 100 + 7 * g, 18, 6, 3)
+                pop.traj_load(g, rows, ends)
+            pop.update()
+        out[key] = [pop.weights(k) for k in range(2)]
+    except Exception as e:
+        out[key] = e
+
+
+def test_two_nfac_handles_two_threads():
+    G = 12
+    ref, got = {}, {}
+    for k in (0, 1):
+        p = build_nfac(G, 3 + k)
+        run_nfac(p, G, 3, ref, k)
+        p.close()
+    pops = [build_nfac(G, 3 + k) for k in (0, 1)]
+    ths = [threading.Thread(target=run_nfac, args=(pops[k], G, 3, got, k)) for k in (0, 1)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths)
+    for p in pops:
+        p.close()
+    for k in (0, 1):
+        assert not isinstance(ref[k], Exception) and not isinstance(got[k], Exception), (ref[k], got[k])
+        for a, b in zip(ref[k], got[k]):
+            assert np.array_equal(a, b), k
